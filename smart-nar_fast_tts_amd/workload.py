@@ -1,0 +1,258 @@
+"""Synthetic workload definition: configs, weights, stats and inputs.
+
+The reference ships no checkpoint, no ``stats.json`` and no test inputs
+(SURVEY.md F6/F8), so every parity and bench run needs a reproducible synthetic
+utterance batch and weight set.  Everything here is derived from a seed through
+``numpy.random.RandomState`` (frozen legacy stream) so the SAME weights can be
+rebuilt in the golden generator (which loads them into the imported reference),
+in the oracle, in the HIP path and on the GPU box without shipping 116 MB.
+
+Key names and tensor layouts follow the reference's ``state_dict``
+(SURVEY.md §8b):  Linear ``[out,in]``, Conv1d ``[out,in,k]``.
+
+This is workload definition, not reference behaviour: in particular the
+duration predictor's output bias is set to ``log(frames_per_phoneme+1)`` because
+plain random-init weights yield ~0.35 frames per phoneme.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+N_SYMBOLS = 360  # len(text.symbols.symbols) in the reference [ran]; vocab = N_SYMBOLS + 1 (transformer/Models.py:40)
+N_MEL = 80
+POSTNET_DIM = 512  # transformer/Layers.py:112-118 (hard-coded)
+POSTNET_K = 5
+POSTNET_N = 5
+
+# config/LJSpeech/model.yaml:1-25 restated (values only; it is data, not code)
+LJSPEECH_MODEL_CONFIG = {
+    "transformer": {
+        "encoder_layer": 4,
+        "encoder_head": 2,
+        "encoder_hidden": 256,
+        "decoder_layer": 4,
+        "decoder_head": 2,
+        "decoder_hidden": 256,
+        "conv_filter_size": 1024,
+        "conv_kernel_size": [9, 1],
+        "encoder_dropout": 0.2,
+        "decoder_dropout": 0.2,
+    },
+    "variance_predictor": {"filter_size": 256, "kernel_size": 3, "dropout": 0.5},
+    "variance_embedding": {
+        # the shipped yaml says pitch "log"; with normalised pitch that gives NaN bins,
+        # so stats below use a positive pitch range which keeps "log" well defined.
+        "pitch_quantization": "log",
+        "energy_quantization": "linear",
+        "n_bins": 256,
+    },
+    "multi_speaker": False,
+    "max_seq_len": 1000,
+}
+
+# config/LJSpeech/preprocess.yaml — only the keys the model constructor reads (model/modules.py:26-46)
+LJSPEECH_PREPROCESS_CONFIG = {
+    "path": {"preprocessed_path": "./preprocessed_data/LJSpeech"},
+    "preprocessing": {
+        "mel": {"n_mel_channels": N_MEL},
+        "pitch": {"feature": "frame_level", "normalization": True},
+        "energy": {"feature": "frame_level", "normalization": True},
+    },
+}
+
+# synthetic stats.json: [min, max, mean, std]
+SYNTH_STATS = {"pitch": [50.0, 600.0, 200.0, 50.0], "energy": [-1.5, 9.0, 30.0, 20.0]}
+
+
+def model_config(name: str = "ljspeech") -> dict:
+    """Named model configs used by BASELINE.json's configs list."""
+    mc = copy.deepcopy(LJSPEECH_MODEL_CONFIG)
+    if name == "ljspeech":
+        return mc
+    if name == "d512":  # BASELINE config 4: d_model=512, 6+6 layers, 8 heads
+        t = mc["transformer"]
+        t.update(encoder_layer=6, decoder_layer=6, encoder_head=8, decoder_head=8,
+                 encoder_hidden=512, decoder_hidden=512)
+        mc["variance_predictor"]["filter_size"] = 256
+        return mc
+    if name == "tiny":  # fixtures: real widths, 1+1 layers
+        t = mc["transformer"]
+        t.update(encoder_layer=1, decoder_layer=1)
+        return mc
+    raise KeyError(name)
+
+
+def preprocess_config() -> dict:
+    return copy.deepcopy(LJSPEECH_PREPROCESS_CONFIG)
+
+
+def sinusoid_table(n_position: int, d_hid: int) -> np.ndarray:
+    """Vectorised restatement of transformer/Models.py:10-30: angle in float64,
+    sin on even / cos on odd columns, cast to float32."""
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)
+    denom = np.power(10000.0, 2 * (j // 2) / d_hid)
+    tab = pos / denom[None, :]
+    tab[:, 0::2] = np.sin(tab[:, 0::2])
+    tab[:, 1::2] = np.cos(tab[:, 1::2])
+    return tab.astype(np.float32)
+
+
+def variance_bins(model_cfg: dict, stats: dict = SYNTH_STATS):
+    """pitch_bins / energy_bins as model/modules.py:48-71 builds them.
+
+    torch.linspace(fp32) then exp in fp32 — reproduced with torch to be
+    bit-identical with what the reference would register as parameters."""
+    import torch
+
+    n_bins = model_cfg["variance_embedding"]["n_bins"]
+    out = {}
+    for name in ("pitch", "energy"):
+        lo, hi = stats[name][:2]
+        if model_cfg["variance_embedding"][f"{name}_quantization"] == "log":
+            b = torch.exp(torch.linspace(np.log(lo), np.log(hi), n_bins - 1))
+        else:
+            b = torch.linspace(lo, hi, n_bins - 1)
+        out[name] = b.numpy().astype(np.float32)
+    return out["pitch"], out["energy"]
+
+
+def _uniform(rs, shape, bound):
+    return rs.uniform(-bound, bound, size=shape).astype(np.float32)
+
+
+def synth_state_dict(model_cfg: dict, seed: int = 0, frames_per_phoneme: float = 8.0,
+                     dur_weight_scale: float = 0.25, stats: dict = SYNTH_STATS) -> "OrderedDict[str, np.ndarray]":
+    """Inference-subset state dict (no ``mel_encoder.*``) with reference key names.
+
+    Distributions follow torch's default initialisers in scale (uniform
+    +-1/sqrt(fan_in) for Linear/Conv, N(0,1) embeddings) but LayerNorm affine
+    and BatchNorm running statistics are made non-trivial so that the parity
+    tests exercise them."""
+    rs = np.random.RandomState(seed)
+    t = model_cfg["transformer"]
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+
+    def linear(prefix, out_f, in_f):
+        b = 1.0 / math.sqrt(in_f)
+        sd[prefix + ".weight"] = _uniform(rs, (out_f, in_f), b)
+        sd[prefix + ".bias"] = _uniform(rs, (out_f,), b)
+
+    def conv(prefix, out_c, in_c, k):
+        b = 1.0 / math.sqrt(in_c * k)
+        sd[prefix + ".weight"] = _uniform(rs, (out_c, in_c, k), b)
+        sd[prefix + ".bias"] = _uniform(rs, (out_c,), b)
+
+    def lnorm(prefix, d):
+        sd[prefix + ".weight"] = (1.0 + 0.1 * rs.standard_normal(d)).astype(np.float32)
+        sd[prefix + ".bias"] = (0.05 * rs.standard_normal(d)).astype(np.float32)
+
+    def stack(prefix, n_layers, d, n_head, d_inner, ks):
+        for i in range(n_layers):
+            p = f"{prefix}.layer_stack.{i}"
+            for w in ("w_qs", "w_ks", "w_vs"):
+                linear(f"{p}.slf_attn.{w}", d, d)
+            lnorm(f"{p}.slf_attn.layer_norm", d)
+            linear(f"{p}.slf_attn.fc", d, d)
+            conv(f"{p}.pos_ffn.w_1", d_inner, d, ks[0])
+            conv(f"{p}.pos_ffn.w_2", d, d_inner, ks[1])
+            lnorm(f"{p}.pos_ffn.layer_norm", d)
+
+    d_enc, d_dec = t["encoder_hidden"], t["decoder_hidden"]
+    n_pos = model_cfg["max_seq_len"] + 1
+    sd["txt_encoder.position_enc"] = sinusoid_table(n_pos, d_enc)[None]
+    emb = rs.standard_normal((N_SYMBOLS + 1, d_enc)).astype(np.float32)
+    emb[0] = 0.0  # padding_idx=0 (transformer/Models.py:55-57)
+    sd["txt_encoder.src_word_emb.weight"] = emb
+    stack("txt_encoder", t["encoder_layer"], d_enc, t["encoder_head"], t["conv_filter_size"], t["conv_kernel_size"])
+
+    pb, eb = variance_bins(model_cfg, stats)
+    sd["variance_adaptor.pitch_bins"] = pb
+    sd["variance_adaptor.energy_bins"] = eb
+    vp = model_cfg["variance_predictor"]
+    for name in ("duration", "pitch", "energy"):
+        p = f"variance_adaptor.{name}_predictor"
+        conv(f"{p}.conv_layer.conv1d_1.conv", vp["filter_size"], d_enc, vp["kernel_size"])
+        lnorm(f"{p}.conv_layer.layer_norm_1", vp["filter_size"])
+        conv(f"{p}.conv_layer.conv1d_2.conv", vp["filter_size"], vp["filter_size"], vp["kernel_size"])
+        lnorm(f"{p}.conv_layer.layer_norm_2", vp["filter_size"])
+        linear(f"{p}.linear_layer", 1, vp["filter_size"])
+    # F2 workload edit: ~frames_per_phoneme frames per phoneme with a moderate spread
+    p = "variance_adaptor.duration_predictor.linear_layer"
+    sd[p + ".weight"] = (sd[p + ".weight"] * dur_weight_scale).astype(np.float32)
+    sd[p + ".bias"] = np.array([math.log(frames_per_phoneme + 1.0)], dtype=np.float32)
+    # spread pitch/energy predictions over several buckets so bucketize is exercised
+    for name, scale, shift in (("pitch", 400.0, 250.0), ("energy", 8.0, 3.0)):
+        p = f"variance_adaptor.{name}_predictor.linear_layer"
+        sd[p + ".weight"] = (sd[p + ".weight"] * scale).astype(np.float32)
+        sd[p + ".bias"] = np.array([shift], dtype=np.float32)
+    n_bins = model_cfg["variance_embedding"]["n_bins"]
+    sd["variance_adaptor.pitch_embedding.weight"] = rs.standard_normal((n_bins, d_enc)).astype(np.float32)
+    sd["variance_adaptor.energy_embedding.weight"] = rs.standard_normal((n_bins, d_enc)).astype(np.float32)
+
+    sd["mel_decoder.position_enc"] = sinusoid_table(n_pos, d_dec)[None]
+    stack("mel_decoder", t["decoder_layer"], d_dec, t["decoder_head"], t["conv_filter_size"], t["conv_kernel_size"])
+
+    linear("mel_linear", N_MEL, d_dec)
+
+    chans = [N_MEL] + [POSTNET_DIM] * (POSTNET_N - 1) + [N_MEL]
+    for i in range(POSTNET_N):
+        conv(f"postnet.convolutions.{i}.0.conv", chans[i + 1], chans[i], POSTNET_K)
+        c = chans[i + 1]
+        sd[f"postnet.convolutions.{i}.1.weight"] = (1.0 + 0.1 * rs.standard_normal(c)).astype(np.float32)
+        sd[f"postnet.convolutions.{i}.1.bias"] = (0.05 * rs.standard_normal(c)).astype(np.float32)
+        sd[f"postnet.convolutions.{i}.1.running_mean"] = (0.05 * rs.standard_normal(c)).astype(np.float32)
+        sd[f"postnet.convolutions.{i}.1.running_var"] = rs.uniform(0.5, 1.5, size=c).astype(np.float32)
+        sd[f"postnet.convolutions.{i}.1.num_batches_tracked"] = np.array(0, dtype=np.int64)
+    return sd
+
+
+def synth_inputs(batch: int, max_src_len: int, seed: int = 0, src_lens=None):
+    """texts ~ randint(1, 361) zero-padded, src_lens (default all = L), speakers = 0."""
+    rs = np.random.RandomState(seed + 1000003)
+    texts = rs.randint(1, N_SYMBOLS + 1, size=(batch, max_src_len)).astype(np.int64)
+    if src_lens is None:
+        lens = np.full((batch,), max_src_len, dtype=np.int64)
+    else:
+        lens = np.asarray(src_lens, dtype=np.int64)
+        assert lens.shape == (batch,) and lens.max() <= max_src_len
+    for b in range(batch):
+        texts[b, lens[b]:] = 0
+    speakers = np.zeros((batch,), dtype=np.int64)
+    return speakers, texts, lens, int(max_src_len)
+
+
+# BASELINE.json "configs" restated as named workloads
+WORKLOADS = {
+    # name: (model config, batch, L, frames/phoneme)
+    "cfg1_single": ("ljspeech", 1, 100, 8.0),
+    "cfg2_b16": ("ljspeech", 16, 128, 8.0),
+    "cfg3_b128_sharded": ("ljspeech", 128, 128, 8.0),
+    "cfg4_d512": ("d512", 64, 128, 8.0),
+    "cfg5_longform": ("ljspeech", 8, 128, 31.0),
+}
+
+
+def algorithmic_flops_per_frame(model_cfg: dict, S_dec: int, S_enc: int, frames_per_phoneme: float) -> float:
+    """SURVEY.md §8(d) FLOP model (2*MAC) per mel frame at T_pad == T."""
+    t = model_cfg["transformer"]
+    vp = model_cfg["variance_predictor"]
+
+    def fft(d, S, d_inner, ks):
+        return 8 * d * d + 4 * S * d + 2 * ks[0] * d * d_inner + 2 * ks[1] * d_inner * d
+
+    def pred(d, f, k):
+        return 2 * k * d * f + 2 * k * f * f + 2 * f
+
+    d_e, d_d = t["encoder_hidden"], t["decoder_hidden"]
+    dec = t["decoder_layer"] * fft(d_d, S_dec, t["conv_filter_size"], t["conv_kernel_size"])
+    enc = t["encoder_layer"] * fft(d_e, S_enc, t["conv_filter_size"], t["conv_kernel_size"]) / frames_per_phoneme
+    pe = 2 * pred(d_e, vp["filter_size"], vp["kernel_size"])
+    du = pred(d_e, vp["filter_size"], vp["kernel_size"]) / frames_per_phoneme
+    post = 2 * POSTNET_K * (N_MEL * POSTNET_DIM + (POSTNET_N - 2) * POSTNET_DIM ** 2 + POSTNET_DIM * N_MEL)
+    lin = 2 * d_d * N_MEL
+    return float(dec + enc + pe + du + post + lin)
