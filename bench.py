@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — whole-job valid mel-frames/sec of the FastSpeech2 inference forward on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward() of the hot path over one synthetic utterance batch already resident in HBM
+(BASELINE.json config 2: batch 16, phoneme_len 128, mel_len ~1024, d_model 256, 4+4 FFT layers).  With N > 1
+every rank runs its own 16-utterance shard (config 3 = 128 utterances over 8 GPUs; weak scaling, no data-path
+collective; weights replicated by ONE RCCL broadcast before the timed region).  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix), v_mfma_f32_32x32x2_f32
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2_b16", help="cfg2_b16 | cfg4_d512 | cfg5_longform | cfg1_single")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--global-pad", action="store_true", help="pad every shard to the global max mel length (all-reduce MAX)")
+    args = ap.parse_args()
+
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd import sharding
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    cfg_name, B_shard, L, fpp = wl.WORKLOADS[args.workload]
+    cfg = wl.model_config(cfg_name)
+    model = FastSpeech2Align(wl.preprocess_config(), cfg).to(dev).eval()
+    sd = wl.synth_state_dict(cfg, seed=0, frames_per_phoneme=fpp) if rank == 0 else None
+    sharding.broadcast_weights(model, sd, src=0)  # N == 1: plain load_state_dict
+
+    # each rank's shard of the global batch (B_shard utterances per GPU): rows [rank*B, (rank+1)*B) of one seeded batch
+    sp, tx, ln, _ = wl.synth_inputs(B_shard * world, L, seed=0)
+    sp, tx, ln, Lmax = sharding.shard_batch(sp, tx, ln, world, rank)
+    speakers, texts, src_lens = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (sp, tx, ln))
+    pad_fn = sharding.global_max if (args.global_pad and world > 1) else None
+
+    def step():
+        return model(speakers, texts, src_lens, Lmax, max_mel_len=pad_fn)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        fence()
+        model.profile_dominant_kernel(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        k_ms, k_flops, k_launches = model.read_profile()
+        model.profile_dominant_kernel(False)
+
+    frames = int(out[9].sum().item())  # valid frames of this rank's shard (sum of mel_lens, never B*T_pad)
+    T_pad = int(out[0].shape[1])
+    stats = torch.tensor([elapsed, float(frames), float(T_pad)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = stats.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_max, frames_total, T_pad_max = float(tmax[0]), float(tsum[1]), int(tmax[2])
+    else:
+        elapsed_max, frames_total, T_pad_max = elapsed, float(frames), T_pad
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    value = frames_total * args.steps / elapsed_max
+    flops_frame = wl.algorithmic_flops_per_frame(cfg, T_pad, L, fpp)
+    achieved_tflops = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    res = {
+        "metric": "mel_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: LJSpeech config, batch {B_shard}/GPU x {args.gpus} GPU, phoneme_len {L}, "
+                               f"T_pad {T_pad_max}, d_model {cfg['transformer']['decoder_hidden']}, "
+                               f"{cfg['transformer']['encoder_layer']}+{cfg['transformer']['decoder_layer']} FFT layers, "
+                               f"random-init weights (seed 0, duration bias log({fpp + 1:g}))",
+                   "global_batch": B_shard * args.gpus, "valid_frames_per_step": int(frames_total),
+                   "padding": "global-pad" if pad_fn else "per-shard",
+                   "algorithmic_mflop_per_frame": round(flops_frame / 1e6, 2),
+                   "end_to_end_tflops": round(flops_frame * value / 1e12, 2)},
+        "roofline": {"bound": "mfma", "kernel": "k_conv_gemm (FFN w_1: Conv1d k=9, d->d_inner, bias+ReLU)",
+                     "achieved": round(achieved_tflops, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved_tflops / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                     "launches": int(k_launches), "avg_launch_ms": round(k_ms / max(k_launches, 1), 4),
+                     "share_of_step_time": round((k_ms * 1e-3) / elapsed if elapsed > 0 else 0.0, 3)},
+    }
+
+    if args.gpus == 1:
+        # p50 per-utterance latency (the second half of BASELINE.json's metric), config 1: B=1, L=100
+        c1, B1, L1, f1 = wl.WORKLOADS["cfg1_single"]
+        if c1 == cfg_name:
+            s1, t1, l1, _ = wl.synth_inputs(B1, L1, seed=0)
+            a1 = [torch.from_numpy(a).to(dev) for a in (s1, t1, l1)]
+            lat = []
+            with torch.no_grad():
+                for i in range(25):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    o1 = model(a1[0], a1[1], a1[2], L1)
+                    torch.cuda.synchronize()
+                    if i >= 5:
+                        lat.append((time.perf_counter() - t0) * 1e3)
+            res["latency"] = {"workload": "cfg1_single: B=1, phoneme_len 100", "p50_ms": round(float(np.median(lat)), 3),
+                              "min_ms": round(min(lat), 3), "max_ms": round(max(lat), 3), "mel_len": int(o1[9][0]), "n": len(lat)}
+
+    if args.gpus == 1 and not args.no_cpu_baseline:
+        # CPU baseline beside it: the oracle (a torch-CPU restatement of the reference forward, "port") on this box's
+        # host cores, same workload, bounded to ~10-30 s.
+        from oracle import fs2_oracle as orc
+
+        cores = min(os.cpu_count() or 1, 64)
+        torch.set_num_threads(cores)
+        w = orc.to_torch_weights(wl.synth_state_dict(cfg, seed=0, frames_per_phoneme=fpp))
+        ci = [torch.from_numpy(np.ascontiguousarray(a)) for a in (sp, tx, ln)]
+        with torch.no_grad():
+            ref = orc.forward(w, cfg, ci[0], ci[1], ci[2], Lmax)  # warm-up
+            n, t0 = 0, time.perf_counter()
+            while n < 5 and (time.perf_counter() - t0) < 20.0:
+                ref = orc.forward(w, cfg, ci[0], ci[1], ci[2], Lmax)
+                n += 1
+            cpu_t = (time.perf_counter() - t0) / n
+        cpu_frames = orc.valid_frames(ref)
+        res["cpu_baseline"] = {"value": cpu_frames / cpu_t, "unit": "frames/s", "cores": cores, "kind": "port",
+                               "sample": f"{n} forward(s) of the same workload ({args.workload}, {cpu_frames} valid frames each), "
+                                         f"{cpu_t:.2f} s per forward, torch {torch.__version__} CPU kernels, {cores} threads"}
+        res["config"]["gpu_vs_oracle_postnet_max_abs"] = float((out[1].cpu() - ref[1]).abs().max()) \
+            if out[1].shape == ref[1].shape else None
+    print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

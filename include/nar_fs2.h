@@ -1,0 +1,141 @@
+/*
+ * nar_fs2.h — C ABI of the MI355X-native FastSpeech2 inference forward.
+ *
+ * The reference (SMART-TTS/SMART-NAR_Fast_TTS) has no FFI / plugin layer: its
+ * boundary for this path is the Python class FastSpeech2Align
+ * (model/fastspeech2_align.py:13-100).  This header is the C-ABI a binding for
+ * that class sits on: plain pointers and sizes, an explicit hipStream_t passed
+ * as void*, int status returns (0 = ok; the Python side raises RuntimeError
+ * with ns_last_error()).  The library allocates NO device memory: weights live
+ * in a caller-provided arena and every call takes a caller-provided workspace
+ * (PyTorch is only the allocator / stream owner on the Python side).
+ *
+ * All tensors are dense row-major float32 unless stated; token ids and lengths
+ * are int64 (what torch.long hands over); masks are uint8 with 1 = padding
+ * (utils/tools.py:89-97: True = padding).
+ */
+#ifndef NAR_FS2_H
+#define NAR_FS2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ns_model ns_model;
+
+/* Mirrors the keys FastSpeech2Align.__init__ reads from model.yaml / preprocess.yaml
+ * (model/fastspeech2_align.py:16-28, model/modules.py:20-77, transformer/Models.py:36-71,176-210)
+ * plus the sizes the reference hard-codes (PostNet 80/512/k5/x5: transformer/Layers.py:112-118). */
+typedef struct ns_config {
+  int32_t n_vocab;          /* len(symbols)+1 = 361, transformer/Models.py:40 */
+  int32_t max_seq_len;      /* 1000 */
+  int32_t d_enc, n_enc_layer, n_enc_head;
+  int32_t d_dec, n_dec_layer, n_dec_head;
+  int32_t d_inner;          /* conv_filter_size 1024 */
+  int32_t ffn_k1, ffn_k2;   /* conv_kernel_size [9, 1] */
+  int32_t vp_filter, vp_kernel; /* variance_predictor 256 / 3 */
+  int32_t n_bins;           /* 256 */
+  int32_t n_mel;            /* 80 */
+  int32_t postnet_dim, postnet_k, postnet_n; /* 512, 5, 5 */
+  int32_t pitch_frame_level, energy_frame_level; /* 1 = frame_level (shipped config), 0 = phoneme_level */
+} ns_config;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+const char* ns_last_error(void);
+int ns_create(const ns_config* cfg, ns_model** out);
+void ns_destroy(ns_model* m);
+
+/* Bytes of device memory the prepared weights need; the caller allocates it (torch.empty) and binds it.
+ * The arena is position independent (offsets only), so rank 0 can fill it and RCCL-broadcast the bytes. */
+size_t ns_arena_bytes(const ns_model* m);
+int ns_bind_arena(ns_model* m, void* dev_arena, size_t bytes);
+
+/* load_state_dict(): one call per state-dict entry, reference key names and torch-native layouts
+ * (Linear [out,in], Conv1d [out,in,k]; utils/model.py:21-22).  `host` is HOST memory.  Unknown
+ * "mel_encoder.*" keys and "*.num_batches_tracked" are accepted and ignored (returns 0);
+ * any other unknown key or a shape mismatch is an error. */
+int ns_set_weight(ns_model* m, const char* name, const float* host, const int64_t* shape, int ndim);
+/* After the last ns_set_weight: repack (conv [out,in,k] -> [out,k,in]; fused QKV), fold eval-mode
+ * BatchNorm into the PostNet convs, upload into the arena.  Fails if an inference key is missing. */
+int ns_finalize_weights(ns_model* m, void* stream);
+/* Non-root ranks: arena bytes arrived by broadcast; mark the model ready without ns_set_weight. */
+int ns_adopt_arena(ns_model* m);
+
+/* ---- the forward: model/fastspeech2_align.py:30-100, inference branch -------------------------- */
+size_t ns_encoder_ws_bytes(const ns_model* m, int B, int L);
+size_t ns_decoder_ws_bytes(const ns_model* m, int B, int L, int T);
+
+/* Phase 1: get_mask_from_lengths + TxtEncoder + duration predictor + rounding + duration scan.
+ * Writes log_d [B,L], d_rounded [B,L] (float32, may hold -0.0), src_mask [B,L], mel_lens [B] (int64).
+ * The encoder output and the duration prefix sums stay in ws_enc for phase 2.
+ * The caller reads mel_lens back (the one unavoidable device->host read: the output tensors are
+ * shaped by max(mel_lens), model/modules.py:136-137) and allocates the phase-2 outputs. */
+int ns_forward_durations(ns_model* m, const int64_t* texts, const int64_t* src_lens, int B, int L,
+                         float d_control, void* ws_enc, size_t ws_enc_bytes,
+                         float* log_d, float* d_rounded, uint8_t* src_mask, int64_t* mel_lens, void* stream);
+
+/* Phase 2: LengthRegulator + frame-level pitch/energy + MelDecoder + mel_linear + PostNet (+ residual).
+ * T must be max(mel_lens) (or a caller-chosen max_mel_len >= it, model/modules.py:128-129 semantics).
+ * Writes mel [B,T,n_mel], postnet_mel [B,T,n_mel], p_pred [B,T], e_pred [B,T], mel_mask [B,T]. */
+/* p_targets / e_targets ([B,T], nullable): forward()'s p_targets / e_targets — when given, the embedding is
+ * taken from bucketize(target) and the prediction is returned unscaled (model/modules.py:82-84,93-95). */
+int ns_forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens, float p_control, float e_control,
+                   const float* p_targets, const float* e_targets, const void* ws_enc, void* ws_dec, size_t ws_dec_bytes,
+                   float* mel, float* postnet_mel, float* p_pred, float* e_pred, uint8_t* mel_mask, void* stream);
+
+/* ---- per-operator entry points (the rows of SURVEY.md §8a; used by the parity tests and by bench.py's
+ *      dominant-kernel timing).  `prefix` is the reference module path, e.g.
+ *      "mel_decoder.layer_stack.0.slf_attn".  lens[b] = valid length of utterance b (keys/rows >= it are padding). */
+size_t ns_op_ws_bytes(const ns_model* m, int B, int S);
+/* a1  utils/tools.py:89-97 */
+int ns_op_mask_from_lengths(const int64_t* lens, int B, int max_len, uint8_t* mask, void* stream);
+/* a2  transformer/Models.py:10-30 */
+int ns_op_sinusoid_table(int n_position, int d_hid, float* out, void* stream);
+/* a3  transformer/Models.py:73-100 */
+int ns_op_txt_encoder(ns_model* m, const int64_t* texts, const int64_t* lens, int B, int L, float* out, void* ws, size_t ws_bytes, void* stream);
+/* a4+a5  transformer/SubLayers.py:29-59, transformer/Modules.py:14-25 */
+int ns_op_multi_head_attention(ns_model* m, const char* prefix, const float* x, const int64_t* lens, int B, int S, float* out, void* ws, size_t ws_bytes, void* stream);
+/* a6  transformer/SubLayers.py:87-95 */
+int ns_op_positionwise_ffn(ns_model* m, const char* prefix, const float* x, int B, int S, float* out, void* ws, size_t ws_bytes, void* stream);
+/* a7  transformer/Layers.py:39-48 */
+int ns_op_fft_block(ns_model* m, const char* prefix, const float* x, const int64_t* lens, int B, int S, float* out, void* ws, size_t ws_bytes, void* stream);
+/* a8  model/modules.py:278-286 */
+int ns_op_variance_predictor(ns_model* m, const char* prefix, const float* x, const int64_t* lens, int B, int S, float* out, void* ws, size_t ws_bytes, void* stream);
+/* a9  model/modules.py:132-135 */
+int ns_op_duration_round(const float* log_d, int n, float d_control, float* d_rounded, void* stream);
+/* a10 model/modules.py:201-230 + utils/tools.py:288-306: step 1 prefix sums + mel_lens, step 2 gather to [B,T,D] */
+int ns_op_duration_scan(const float* d_rounded, int B, int L, int32_t* cum, int64_t* mel_lens, void* stream);
+int ns_op_length_regulate(const float* x, const int32_t* cum, int B, int L, int D, int T, float* out, void* stream);
+/* a11 model/modules.py:80-100,139-149: which = 0 pitch, 1 energy; x_out = x + embedding[bucketize(pred*control)] (unmasked add) */
+int ns_op_variance_embedding(ns_model* m, int which, const float* x, const int64_t* lens, int B, int S, float control, const float* target /* nullable */, float* pred, float* x_out, void* ws, size_t ws_bytes, void* stream);
+/* a11 torch.bucketize(values, bins, right=False) as called at model/modules.py:86-88,97-99 (the same device routine
+ * the fused ns_op_variance_embedding kernel uses); idx[i] in [0, n_edges] */
+int ns_op_bucketize(const float* values, int n, const float* bins, int n_edges, int64_t* idx, void* stream);
+/* a12 model/modules.py:166-192 (dead code in the reference forward): out [B,T_out,D] (rows >= T zero),
+ * w [B,L,T] (may be NULL), s: B*(L+1) floats — s[0..B) = sum of durations, the rest is scratch for the Gaussian centres */
+int ns_op_gaussian_upsampling(const float* x, const float* durations, int B, int L, int D, int T, int T_out, float* out, float* s, float* w, void* stream);
+/* a13 transformer/Models.py:212-244 */
+int ns_op_mel_decoder(ns_model* m, const float* x, const int64_t* lens, int B, int T, float* out, void* ws, size_t ws_bytes, void* stream);
+/* a14 model/fastspeech2_align.py:24-27,83 */
+int ns_op_mel_linear(ns_model* m, const float* x, int B, int T, float* out, void* stream);
+/* a15 transformer/Layers.py:169-177 (returns postnet(x) WITHOUT the residual, like PostNet.forward) */
+int ns_op_postnet(ns_model* m, const float* mel, int B, int T, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* bench.py's roofline leg: launches only the dominant kernel (the FFN k=9 Conv1D-as-GEMM of `prefix`.w_1,
+ * bias+ReLU epilogue) on [B,S,d] -> [B,S,d_inner]; flops = 2*B*S*k*d*d_inner. */
+int ns_op_ffn_conv1(ns_model* m, const char* prefix, const float* x, int B, int S, float* hidden, void* stream);
+
+/* Measurement hook for bench.py's roofline leg: while enabled, every launch of the dominant kernel (the FFT blocks'
+ * k=9 Conv1D-as-GEMM, PositionwiseFeedForward.w_1, transformer/SubLayers.py:70-75) inside ns_forward_* is bracketed
+ * by hipEvents on the launch stream.  ns_profile_read waits for them and returns the summed kernel time, the summed
+ * algorithmic flops (2*rows*k*d*d_inner per launch) and the launch count, then resets the counters. */
+int ns_profile_enable(ns_model* m, int on);
+int ns_profile_read(ns_model* m, double* total_ms, double* total_flops, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAR_FS2_H */

@@ -1,0 +1,705 @@
+// C-ABI (include/nar_fs2.h) over the gfx950 kernels: weight registry/packing, workspace planning and the
+// launch sequence of the FastSpeech2Align inference forward (model/fastspeech2_align.py:30-100).
+// Host-side only; every byte of device memory is provided by the caller.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/nar_fs2.h"
+#include "kernels.h"
+
+using namespace ns;
+
+static thread_local std::string g_err;
+static int fail(const std::string& s) { g_err = s; return 1; }
+#define NS_HIP(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));              \
+  } while (0)
+#define NS_TRY(expr)              \
+  do {                            \
+    int rc_ = (expr);             \
+    if (rc_) return rc_;          \
+  } while (0)
+
+namespace {
+
+struct LayerW { size_t qkv_w, qkv_b, fc_w, fc_b, ln1_g, ln1_b, w1, w1_b, w2, w2_b, ln2_g, ln2_b; };
+struct PredW { size_t c1, c1_b, ln1_g, ln1_b, c2, c2_b, ln2_g, ln2_b, lin_w, lin_b; int cin; };
+struct PostW { size_t w, b; int cin, cout; };
+
+struct Arena {
+  size_t n = 0;  // floats
+  size_t take(size_t floats) { size_t o = n; n += (floats + 63) & ~(size_t)63; return o; }
+};
+
+struct Staged { std::vector<int64_t> shape; std::vector<float> data; bool set = false; bool optional = false; };
+
+}  // namespace
+
+struct ns_model {
+  ns_config cfg;
+  std::vector<LayerW> enc, dec;
+  PredW pred[3];
+  size_t emb, enc_pos, dec_pos, pitch_bins, energy_bins, pitch_emb, energy_emb, mel_w, mel_b;
+  std::vector<PostW> post;
+  Arena ar;
+  float* arena = nullptr;
+  bool ready = false;
+  std::map<std::string, Staged> staged;
+  const float* P(size_t off) const { return arena + off; }
+  // optional HIP-event timing of the dominant kernel (FFN k=9 Conv1D-as-GEMM) inside the real forward
+  bool prof = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+  size_t prof_used = 0;
+  double prof_flops = 0.0;
+};
+
+static const char* kPredNames[3] = {"duration", "pitch", "energy"};
+
+static void expect(ns_model* m, const std::string& name, std::vector<int64_t> shape, bool optional = false) {
+  Staged s; s.shape = std::move(shape); s.optional = optional; m->staged[name] = std::move(s);
+}
+
+static void plan_stack(ns_model* m, const char* prefix, int n_layer, int d, std::vector<LayerW>& out) {
+  const ns_config& c = m->cfg;
+  for (int i = 0; i < n_layer; ++i) {
+    std::string p = std::string(prefix) + ".layer_stack." + std::to_string(i);
+    for (const char* w : {"w_qs", "w_ks", "w_vs", "fc"}) {
+      expect(m, p + ".slf_attn." + w + ".weight", {d, d});
+      expect(m, p + ".slf_attn." + w + ".bias", {d});
+    }
+    expect(m, p + ".slf_attn.layer_norm.weight", {d});
+    expect(m, p + ".slf_attn.layer_norm.bias", {d});
+    expect(m, p + ".pos_ffn.w_1.weight", {c.d_inner, d, c.ffn_k1});
+    expect(m, p + ".pos_ffn.w_1.bias", {c.d_inner});
+    expect(m, p + ".pos_ffn.w_2.weight", {d, c.d_inner, c.ffn_k2});
+    expect(m, p + ".pos_ffn.w_2.bias", {d});
+    expect(m, p + ".pos_ffn.layer_norm.weight", {d});
+    expect(m, p + ".pos_ffn.layer_norm.bias", {d});
+    LayerW L;
+    L.qkv_w = m->ar.take((size_t)3 * d * d); L.qkv_b = m->ar.take(3 * d);
+    L.fc_w = m->ar.take((size_t)d * d); L.fc_b = m->ar.take(d);
+    L.ln1_g = m->ar.take(d); L.ln1_b = m->ar.take(d);
+    L.w1 = m->ar.take((size_t)c.d_inner * c.ffn_k1 * d); L.w1_b = m->ar.take(c.d_inner);
+    L.w2 = m->ar.take((size_t)d * c.ffn_k2 * c.d_inner); L.w2_b = m->ar.take(d);
+    L.ln2_g = m->ar.take(d); L.ln2_b = m->ar.take(d);
+    out.push_back(L);
+  }
+}
+
+extern "C" const char* ns_last_error(void) { return g_err.c_str(); }
+
+extern "C" int ns_create(const ns_config* cfg, ns_model** out) {
+  if (!cfg || !out) return fail("ns_create: null argument");
+  const ns_config& c = *cfg;
+  if (c.d_enc != c.d_dec) return fail("ns_create: encoder_hidden != decoder_hidden is not supported (the variance adaptor adds encoder-width embeddings to the decoder input)");
+  if (c.d_enc % 32 || c.d_inner % 32 || c.vp_filter % 32 || c.postnet_dim % 32 || c.n_mel % 16)
+    return fail("ns_create: channel widths must be multiples of 32 (n_mel: 16)");
+  for (int pair = 0; pair < 2; ++pair) {
+    const int d = pair ? c.d_dec : c.d_enc, h = pair ? c.n_dec_head : c.n_enc_head;
+    if (h <= 0 || d % h) return fail("ns_create: hidden size not divisible by head count");
+    const int dk = d / h;
+    if (dk != 32 && dk != 64 && dk != 128) return fail("ns_create: d_k must be 32, 64 or 128");
+  }
+  if (!(c.ffn_k1 & 1) || !(c.ffn_k2 & 1) || !(c.vp_kernel & 1) || !(c.postnet_k & 1))
+    return fail("ns_create: kernel sizes must be odd");
+  if (c.vp_kernel != 3) return fail("ns_create: variance predictor conv1d_2 hard-codes padding=1 (model/modules.py:267); kernel_size must be 3");
+  if (!c.pitch_frame_level || !c.energy_frame_level)
+    return fail("ns_create: phoneme_level pitch/energy is not built yet (SURVEY.md §8 f4); the shipped config is frame_level");
+  ns_model* m = new ns_model();
+  m->cfg = c;
+  const int d = c.d_enc, npos = c.max_seq_len + 1;
+  expect(m, "txt_encoder.src_word_emb.weight", {c.n_vocab, d});
+  expect(m, "txt_encoder.position_enc", {1, npos, d}, true);
+  expect(m, "mel_decoder.position_enc", {1, npos, c.d_dec}, true);
+  m->emb = m->ar.take((size_t)c.n_vocab * d);
+  m->enc_pos = m->ar.take((size_t)npos * d);
+  m->dec_pos = m->ar.take((size_t)npos * c.d_dec);
+  plan_stack(m, "txt_encoder", c.n_enc_layer, d, m->enc);
+  plan_stack(m, "mel_decoder", c.n_dec_layer, c.d_dec, m->dec);
+  const int F = c.vp_filter, K = c.vp_kernel;
+  for (int i = 0; i < 3; ++i) {
+    std::string p = std::string("variance_adaptor.") + kPredNames[i] + "_predictor";
+    expect(m, p + ".conv_layer.conv1d_1.conv.weight", {F, d, K});
+    expect(m, p + ".conv_layer.conv1d_1.conv.bias", {F});
+    expect(m, p + ".conv_layer.layer_norm_1.weight", {F});
+    expect(m, p + ".conv_layer.layer_norm_1.bias", {F});
+    expect(m, p + ".conv_layer.conv1d_2.conv.weight", {F, F, K});
+    expect(m, p + ".conv_layer.conv1d_2.conv.bias", {F});
+    expect(m, p + ".conv_layer.layer_norm_2.weight", {F});
+    expect(m, p + ".conv_layer.layer_norm_2.bias", {F});
+    expect(m, p + ".linear_layer.weight", {1, F});
+    expect(m, p + ".linear_layer.bias", {1});
+    PredW& w = m->pred[i];
+    w.cin = d;
+    w.c1 = m->ar.take((size_t)F * K * d); w.c1_b = m->ar.take(F);
+    w.ln1_g = m->ar.take(F); w.ln1_b = m->ar.take(F);
+    w.c2 = m->ar.take((size_t)F * K * F); w.c2_b = m->ar.take(F);
+    w.ln2_g = m->ar.take(F); w.ln2_b = m->ar.take(F);
+    w.lin_w = m->ar.take(F); w.lin_b = m->ar.take(1);
+  }
+  expect(m, "variance_adaptor.pitch_bins", {c.n_bins - 1});
+  expect(m, "variance_adaptor.energy_bins", {c.n_bins - 1});
+  expect(m, "variance_adaptor.pitch_embedding.weight", {c.n_bins, d});
+  expect(m, "variance_adaptor.energy_embedding.weight", {c.n_bins, d});
+  m->pitch_bins = m->ar.take(c.n_bins); m->energy_bins = m->ar.take(c.n_bins);
+  m->pitch_emb = m->ar.take((size_t)c.n_bins * d); m->energy_emb = m->ar.take((size_t)c.n_bins * d);
+  expect(m, "mel_linear.weight", {c.n_mel, c.d_dec});
+  expect(m, "mel_linear.bias", {c.n_mel});
+  m->mel_w = m->ar.take((size_t)c.n_mel * c.d_dec); m->mel_b = m->ar.take(c.n_mel);
+  for (int i = 0; i < c.postnet_n; ++i) {
+    const int cin = i == 0 ? c.n_mel : c.postnet_dim, cout = i == c.postnet_n - 1 ? c.n_mel : c.postnet_dim;
+    std::string p = "postnet.convolutions." + std::to_string(i);
+    expect(m, p + ".0.conv.weight", {cout, cin, c.postnet_k});
+    expect(m, p + ".0.conv.bias", {cout});
+    for (const char* s : {"weight", "bias", "running_mean", "running_var"}) expect(m, p + ".1." + s, {cout});
+    PostW w; w.cin = cin; w.cout = cout;
+    w.w = m->ar.take((size_t)cout * c.postnet_k * cin); w.b = m->ar.take(cout);
+    m->post.push_back(w);
+  }
+  *out = m;
+  return 0;
+}
+
+extern "C" void ns_destroy(ns_model* m) { delete m; }
+extern "C" size_t ns_arena_bytes(const ns_model* m) { return m ? m->ar.n * sizeof(float) : 0; }
+
+extern "C" int ns_bind_arena(ns_model* m, void* dev, size_t bytes) {
+  if (!m || !dev) return fail("ns_bind_arena: null argument");
+  if (bytes < ns_arena_bytes(m)) return fail("ns_bind_arena: arena too small");
+  if ((uintptr_t)dev & 255) return fail("ns_bind_arena: arena must be 256-byte aligned");
+  m->arena = (float*)dev;
+  m->ready = false;
+  return 0;
+}
+
+extern "C" int ns_adopt_arena(ns_model* m) {
+  if (!m || !m->arena) return fail("ns_adopt_arena: no arena bound");
+  m->staged.clear();
+  m->ready = true;
+  return 0;
+}
+
+static bool starts_with(const std::string& s, const char* p) { return s.rfind(p, 0) == 0; }
+static bool ends_with(const std::string& s, const char* p) {
+  size_t n = strlen(p); return s.size() >= n && s.compare(s.size() - n, n, p) == 0;
+}
+
+extern "C" int ns_set_weight(ns_model* m, const char* name_c, const float* host, const int64_t* shape, int ndim) {
+  if (!m || !name_c) return fail("ns_set_weight: null argument");
+  std::string name(name_c);
+  // training-only aligner weights live in every checkpoint; accept and ignore
+  if (starts_with(name, "mel_encoder.") || ends_with(name, ".num_batches_tracked")) return 0;
+  auto it = m->staged.find(name);
+  if (it == m->staged.end()) return fail("ns_set_weight: unexpected key '" + name + "'");
+  Staged& s = it->second;
+  if ((int)s.shape.size() != ndim) return fail("ns_set_weight: rank mismatch for '" + name + "'");
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    if (shape[i] != s.shape[i]) {
+      return fail("ns_set_weight: size mismatch for '" + name + "': dim " + std::to_string(i) + " is " +
+                  std::to_string(shape[i]) + ", expected " + std::to_string(s.shape[i]));
+    }
+    n *= (size_t)shape[i];
+  }
+  if (!host) return fail("ns_set_weight: null data for '" + name + "'");
+  s.data.assign(host, host + n);
+  s.set = true;
+  m->ready = false;
+  return 0;
+}
+
+// conv weight [out][in][k] (torch) -> [out][k][in] (tap-major K for the implicit GEMM), optional per-out scale
+static void pack_conv(const std::vector<float>& w, int cout, int cin, int k, float* dst, const double* scale = nullptr) {
+  for (int o = 0; o < cout; ++o)
+    for (int c = 0; c < cin; ++c)
+      for (int j = 0; j < k; ++j) {
+        double v = w[((size_t)o * cin + c) * k + j];
+        if (scale) v *= scale[o];
+        dst[((size_t)o * k + j) * cin + c] = (float)v;
+      }
+}
+
+static void host_sinusoid(int n_pos, int d, float* dst) {  // transformer/Models.py:10-30
+  for (int p = 0; p < n_pos; ++p)
+    for (int j = 0; j < d; ++j) {
+      const double ang = (double)p / std::pow(10000.0, (double)(2 * (j / 2)) / (double)d);
+      dst[(size_t)p * d + j] = (float)((j & 1) ? std::cos(ang) : std::sin(ang));
+    }
+}
+
+extern "C" int ns_finalize_weights(ns_model* m, void* stream) {
+  if (!m) return fail("ns_finalize_weights: null model");
+  if (!m->arena) return fail("ns_finalize_weights: bind an arena first (ns_bind_arena)");
+  std::string missing;
+  for (auto& kv : m->staged)
+    if (!kv.second.set && !kv.second.optional) missing += (missing.empty() ? "" : ", ") + kv.first;
+  if (!missing.empty()) return fail("ns_finalize_weights: missing keys: " + missing);
+  const ns_config& c = m->cfg;
+  std::vector<float> img(m->ar.n, 0.f);
+  auto S = [&](const std::string& k) -> const std::vector<float>& { return m->staged[k].data; };
+  auto cp = [&](size_t off, const std::string& k) { const auto& v = S(k); memcpy(&img[off], v.data(), v.size() * sizeof(float)); };
+
+  cp(m->emb, "txt_encoder.src_word_emb.weight");
+  const int npos = c.max_seq_len + 1;
+  if (m->staged["txt_encoder.position_enc"].set) cp(m->enc_pos, "txt_encoder.position_enc");
+  else host_sinusoid(npos, c.d_enc, &img[m->enc_pos]);
+  if (m->staged["mel_decoder.position_enc"].set) cp(m->dec_pos, "mel_decoder.position_enc");
+  else host_sinusoid(npos, c.d_dec, &img[m->dec_pos]);
+
+  auto do_stack = [&](const char* prefix, std::vector<LayerW>& Ls, int d) {
+    for (size_t i = 0; i < Ls.size(); ++i) {
+      const LayerW& L = Ls[i];
+      std::string p = std::string(prefix) + ".layer_stack." + std::to_string(i);
+      const char* qkv[3] = {"w_qs", "w_ks", "w_vs"};
+      for (int t = 0; t < 3; ++t) {  // fused projection: rows [0,d) = Q, [d,2d) = K, [2d,3d) = V
+        memcpy(&img[L.qkv_w + (size_t)t * d * d], S(p + ".slf_attn." + qkv[t] + ".weight").data(), (size_t)d * d * 4);
+        memcpy(&img[L.qkv_b + (size_t)t * d], S(p + ".slf_attn." + qkv[t] + ".bias").data(), (size_t)d * 4);
+      }
+      cp(L.fc_w, p + ".slf_attn.fc.weight"); cp(L.fc_b, p + ".slf_attn.fc.bias");
+      cp(L.ln1_g, p + ".slf_attn.layer_norm.weight"); cp(L.ln1_b, p + ".slf_attn.layer_norm.bias");
+      pack_conv(S(p + ".pos_ffn.w_1.weight"), c.d_inner, d, c.ffn_k1, &img[L.w1]); cp(L.w1_b, p + ".pos_ffn.w_1.bias");
+      pack_conv(S(p + ".pos_ffn.w_2.weight"), d, c.d_inner, c.ffn_k2, &img[L.w2]); cp(L.w2_b, p + ".pos_ffn.w_2.bias");
+      cp(L.ln2_g, p + ".pos_ffn.layer_norm.weight"); cp(L.ln2_b, p + ".pos_ffn.layer_norm.bias");
+    }
+  };
+  do_stack("txt_encoder", m->enc, c.d_enc);
+  do_stack("mel_decoder", m->dec, c.d_dec);
+
+  for (int i = 0; i < 3; ++i) {
+    const PredW& w = m->pred[i];
+    std::string p = std::string("variance_adaptor.") + kPredNames[i] + "_predictor";
+    pack_conv(S(p + ".conv_layer.conv1d_1.conv.weight"), c.vp_filter, w.cin, c.vp_kernel, &img[w.c1]);
+    cp(w.c1_b, p + ".conv_layer.conv1d_1.conv.bias");
+    cp(w.ln1_g, p + ".conv_layer.layer_norm_1.weight"); cp(w.ln1_b, p + ".conv_layer.layer_norm_1.bias");
+    pack_conv(S(p + ".conv_layer.conv1d_2.conv.weight"), c.vp_filter, c.vp_filter, c.vp_kernel, &img[w.c2]);
+    cp(w.c2_b, p + ".conv_layer.conv1d_2.conv.bias");
+    cp(w.ln2_g, p + ".conv_layer.layer_norm_2.weight"); cp(w.ln2_b, p + ".conv_layer.layer_norm_2.bias");
+    cp(w.lin_w, p + ".linear_layer.weight"); cp(w.lin_b, p + ".linear_layer.bias");
+  }
+  cp(m->pitch_bins, "variance_adaptor.pitch_bins"); cp(m->energy_bins, "variance_adaptor.energy_bins");
+  cp(m->pitch_emb, "variance_adaptor.pitch_embedding.weight"); cp(m->energy_emb, "variance_adaptor.energy_embedding.weight");
+  cp(m->mel_w, "mel_linear.weight"); cp(m->mel_b, "mel_linear.bias");
+
+  // PostNet: fold eval-mode BatchNorm1d (running stats, eps 1e-5) into the conv (transformer/Layers.py:120-167)
+  for (size_t i = 0; i < m->post.size(); ++i) {
+    const PostW& w = m->post[i];
+    std::string p = "postnet.convolutions." + std::to_string(i);
+    const auto &g = S(p + ".1.weight"), &b = S(p + ".1.bias"), &mu = S(p + ".1.running_mean"), &var = S(p + ".1.running_var");
+    const auto& cb = S(p + ".0.conv.bias");
+    std::vector<double> sc(w.cout);
+    for (int o = 0; o < w.cout; ++o) {
+      sc[o] = (double)g[o] / std::sqrt((double)var[o] + 1e-5);
+      img[w.b + o] = (float)(((double)cb[o] - (double)mu[o]) * sc[o] + (double)b[o]);
+    }
+    pack_conv(S(p + ".0.conv.weight"), w.cout, w.cin, c.postnet_k, &img[w.w], sc.data());
+  }
+  hipStream_t st = (hipStream_t)stream;
+  NS_HIP(hipMemcpyAsync(m->arena, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  NS_HIP(hipStreamSynchronize(st));  // img is a local; also makes load_state_dict() synchronous like the reference's
+  for (auto& kv : m->staged) { kv.second.data.clear(); kv.second.data.shrink_to_fit(); }
+  m->ready = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- workspace
+namespace {
+struct Bump {
+  char* base; size_t off = 0, cap;
+  Bump(void* p, size_t c) : base((char*)p), cap(c) {}
+  float* f(size_t n) { return (float*)raw(n * sizeof(float)); }
+  void* raw(size_t bytes) {
+    size_t o = off; off += (bytes + 255) & ~(size_t)255;
+    return base ? base + o : nullptr;
+  }
+};
+
+struct Scratch {  // per-stack temporaries for M rows
+  float *xa, *xb, *qkv, *att, *t1, *x1, *hid, *vp1, *vp2, *pos_ext;
+};
+
+static size_t imax(size_t a, size_t b) { return a > b ? a : b; }
+
+static Scratch carve(const ns_config& c, Bump& bp, size_t M, int S) {
+  Scratch s;
+  const size_t d = c.d_enc;
+  s.xa = bp.f(M * d); s.xb = bp.f(M * d);
+  s.qkv = bp.f(M * 3 * d); s.att = bp.f(M * d); s.t1 = bp.f(M * d); s.x1 = bp.f(M * d);
+  s.hid = bp.f(M * imax(c.d_inner, 2 * (size_t)c.postnet_dim));
+  s.vp1 = bp.f(M * c.vp_filter); s.vp2 = bp.f(M * c.vp_filter);
+  s.pos_ext = S > c.max_seq_len ? bp.f((size_t)S * d) : nullptr;
+  return s;
+}
+}  // namespace
+
+extern "C" size_t ns_op_ws_bytes(const ns_model* m, int B, int S) {
+  if (!m || B <= 0 || S <= 0) return 256;
+  Bump bp(nullptr, 0);
+  carve(m->cfg, bp, (size_t)B * S, S);
+  return bp.off + 256;
+}
+extern "C" size_t ns_encoder_ws_bytes(const ns_model* m, int B, int L) {
+  if (!m || B <= 0 || L <= 0) return 256;
+  Bump bp(nullptr, 0);
+  bp.f((size_t)B * L * m->cfg.d_enc);  // encoder output (kept for phase 2)
+  bp.raw((size_t)B * L * sizeof(int32_t));  // duration prefix sums (kept for phase 2)
+  carve(m->cfg, bp, (size_t)B * L, L);
+  return bp.off + 256;
+}
+extern "C" size_t ns_decoder_ws_bytes(const ns_model* m, int B, int L, int T) {
+  (void)L;
+  return ns_op_ws_bytes(m, B, T);
+}
+
+// ------------------------------------------------------------------------------------------- building blocks
+static int check_ready(const ns_model* m) {
+  if (!m) return fail("null model");
+  if (!m->ready) return fail("weights not loaded: call ns_set_weight for every key, then ns_finalize_weights (or ns_adopt_arena)");
+  return 0;
+}
+
+static int gemm(const float* X, int ldx, const float* W, const float* bias, const float* resid, int ldr, float* Y, int ldy,
+                int M, int N, int Cin, int KW, int S, int act, hipStream_t st) {
+  ConvGemm p;
+  p.X = X; p.ldx = ldx; p.W = W; p.bias = bias; p.resid = resid; p.ldr = ldr; p.Y = Y; p.ldy = ldy; p.lens = nullptr;
+  p.M = M; p.N = N; p.Cin = Cin; p.KW = KW; p.pad = (KW - 1) / 2; p.S = S; p.act = act;
+  NS_HIP(launch_conv_gemm(p, st));
+  return 0;
+}
+
+// MultiHeadAttention.forward (transformer/SubLayers.py:29-59); out = LayerNorm(fc(attn) + x), NOT yet masked
+static int mha(const ns_model* m, const LayerW& L, int d, int H, const float* x, const long long* lens, int B, int S,
+               float* out, bool mask_rows, Scratch& sc, hipStream_t st) {
+  const int M = B * S;
+  NS_TRY(gemm(x, d, m->P(L.qkv_w), m->P(L.qkv_b), nullptr, 0, sc.qkv, 3 * d, M, 3 * d, d, 1, S, ACT_NONE, st));
+  NS_HIP(launch_attention(sc.qkv, lens, B, S, H, d / H, sc.att, st));
+  NS_TRY(gemm(sc.att, d, m->P(L.fc_w), m->P(L.fc_b), x, d, sc.t1, d, M, d, d, 1, S, ACT_NONE, st));
+  NS_HIP(launch_layernorm(sc.t1, m->P(L.ln1_g), m->P(L.ln1_b), out, M, d, S, mask_rows ? lens : nullptr, st));
+  return 0;
+}
+
+// PositionwiseFeedForward.forward (transformer/SubLayers.py:87-95)
+static int ffn(const ns_model* m, const LayerW& L, int d, const float* x, const long long* lens, int B, int S, float* out,
+               bool mask_rows, Scratch& sc, hipStream_t st) {
+  const ns_config& c = m->cfg;
+  const int M = B * S;
+  ns_model* mm = const_cast<ns_model*>(m);
+  const bool prof = m->prof;
+  if (prof) {
+    if (mm->prof_used == mm->prof_ev.size()) {
+      hipEvent_t a, b;
+      NS_HIP(hipEventCreate(&a));
+      NS_HIP(hipEventCreate(&b));
+      mm->prof_ev.emplace_back(a, b);
+    }
+    NS_HIP(hipEventRecord(mm->prof_ev[mm->prof_used].first, st));
+  }
+  NS_TRY(gemm(x, d, m->P(L.w1), m->P(L.w1_b), nullptr, 0, sc.hid, c.d_inner, M, c.d_inner, d, c.ffn_k1, S, ACT_RELU, st));
+  if (prof) {
+    NS_HIP(hipEventRecord(mm->prof_ev[mm->prof_used].second, st));
+    mm->prof_used++;
+    mm->prof_flops += 2.0 * (double)M * (double)c.ffn_k1 * (double)d * (double)c.d_inner;
+  }
+  NS_TRY(gemm(sc.hid, c.d_inner, m->P(L.w2), m->P(L.w2_b), x, d, sc.t1, d, M, d, c.d_inner, c.ffn_k2, S, ACT_NONE, st));
+  NS_HIP(launch_layernorm(sc.t1, m->P(L.ln2_g), m->P(L.ln2_b), out, M, d, S, mask_rows ? lens : nullptr, st));
+  return 0;
+}
+
+// FFTBlock.forward (transformer/Layers.py:39-48): both masked_fill's are fused into the LayerNorm kernels
+static int fft_block(const ns_model* m, const LayerW& L, int d, int H, const float* x, const long long* lens, int B, int S,
+                     float* out, Scratch& sc, hipStream_t st) {
+  NS_TRY(mha(m, L, d, H, x, lens, B, S, sc.x1, true, sc, st));
+  NS_TRY(ffn(m, L, d, sc.x1, lens, B, S, out, true, sc, st));
+  return 0;
+}
+
+// position rows [0,S): cached parameter when S <= max_seq_len, else rebuilt (transformer/Models.py:82-91,218-235)
+static int position_rows(const ns_model* m, size_t cached_off, int S, int d, Scratch& sc, const float** pos, hipStream_t st) {
+  if (S > m->cfg.max_seq_len) {
+    NS_HIP(launch_sinusoid(S, d, sc.pos_ext, st));
+    *pos = sc.pos_ext;
+  } else {
+    *pos = m->P(cached_off);
+  }
+  return 0;
+}
+
+// VariancePredictor.forward (model/modules.py:278-286) with the optional fused embedding add
+static int predictor(const ns_model* m, const PredW& w, const float* x, const long long* lens, int B, int S, float control,
+                     const float* target,
+                     float* pred, const float* bins, const float* emb, const float* pos, float* x_out, Scratch& sc,
+                     hipStream_t st) {
+  const ns_config& c = m->cfg;
+  const int M = B * S, F = c.vp_filter;
+  NS_TRY(gemm(x, w.cin, m->P(w.c1), m->P(w.c1_b), nullptr, 0, sc.vp1, F, M, F, w.cin, c.vp_kernel, S, ACT_RELU, st));
+  NS_HIP(launch_layernorm(sc.vp1, m->P(w.ln1_g), m->P(w.ln1_b), sc.vp2, M, F, S, nullptr, st));
+  NS_TRY(gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st));
+  NS_HIP(launch_ln_linear_embed(sc.vp1, m->P(w.ln2_g), m->P(w.ln2_b), m->P(w.lin_w), m->P(w.lin_b), pred, M, F, S, lens,
+                                control, target, bins, c.n_bins, emb, x, pos, x_out, w.cin, st));
+  return 0;
+}
+
+// PostNet.forward (transformer/Layers.py:169-177); resid != nullptr adds `+ output` of fastspeech2_align.py:85
+static int postnet(const ns_model* m, const float* mel, int B, int T, const float* resid, float* out, Scratch& sc, hipStream_t st) {
+  const ns_config& c = m->cfg;
+  const int M = B * T;
+  float* ping = sc.hid;
+  float* pong = sc.hid + (size_t)M * c.postnet_dim;
+  const float* cur = mel;
+  int ld = c.n_mel;
+  for (size_t i = 0; i < m->post.size(); ++i) {
+    const PostW& w = m->post[i];
+    const bool last = i + 1 == m->post.size();
+    float* dst = last ? out : ((i & 1) ? pong : ping);
+    NS_TRY(gemm(cur, ld, m->P(w.w), m->P(w.b), last ? resid : nullptr, c.n_mel, dst, w.cout, M, w.cout, w.cin, c.postnet_k, T,
+                last ? ACT_NONE : ACT_TANH, st));
+    cur = dst;
+    ld = w.cout;
+  }
+  return 0;
+}
+
+static int encoder(const ns_model* m, const long long* texts, const long long* lens, int B, int L, float* out, Scratch& sc,
+                   hipStream_t st) {
+  const ns_config& c = m->cfg;
+  const int M = B * L, d = c.d_enc;
+  const float* pos;
+  NS_TRY(position_rows(m, m->enc_pos, L, d, sc, &pos, st));
+  float* cur = m->enc.empty() ? out : sc.xa;
+  NS_HIP(launch_embed_pos(texts, m->P(m->emb), pos, cur, M, L, d, st));
+  for (size_t i = 0; i < m->enc.size(); ++i) {
+    float* dst = (i + 1 == m->enc.size()) ? out : (cur == sc.xa ? sc.xb : sc.xa);
+    NS_TRY(fft_block(m, m->enc[i], d, c.n_enc_head, cur, lens, B, L, dst, sc, st));
+    cur = dst;
+  }
+  return 0;
+}
+
+// MelDecoder's layer stack on an input that already carries the position rows
+static int decoder_stack(const ns_model* m, float* x, const long long* lens, int B, int T, float* out, Scratch& sc, hipStream_t st) {
+  const ns_config& c = m->cfg;
+  float* cur = x;
+  float* alt = (x == sc.xa) ? sc.xb : sc.xa;
+  for (size_t i = 0; i < m->dec.size(); ++i) {
+    float* dst = (i + 1 == m->dec.size()) ? out : alt;
+    NS_TRY(fft_block(m, m->dec[i], c.d_dec, c.n_dec_head, cur, lens, B, T, dst, sc, st));
+    if (dst != out) { alt = cur; cur = dst; }
+  }
+  if (m->dec.empty() && out != x) NS_HIP(hipMemcpyAsync(out, x, (size_t)B * T * c.d_dec * 4, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- the forward
+extern "C" int ns_forward_durations(ns_model* m, const int64_t* texts, const int64_t* src_lens, int B, int L, float d_control,
+                                    void* ws_enc, size_t ws_bytes, float* log_d, float* d_rounded, uint8_t* src_mask,
+                                    int64_t* mel_lens, void* stream) {
+  NS_TRY(check_ready(m));
+  if (B <= 0 || L <= 0) return fail("ns_forward_durations: empty batch");
+  if (ws_bytes < ns_encoder_ws_bytes(m, B, L)) return fail("ns_forward_durations: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const ns_config& c = m->cfg;
+  Bump bp(ws_enc, ws_bytes);
+  float* enc_out = bp.f((size_t)B * L * c.d_enc);
+  int32_t* cum = (int32_t*)bp.raw((size_t)B * L * sizeof(int32_t));
+  Scratch sc = carve(c, bp, (size_t)B * L, L);
+  const long long* lens = (const long long*)src_lens;
+  NS_HIP(launch_mask_from_lengths(lens, B, L, src_mask, st));
+  NS_TRY(encoder(m, (const long long*)texts, lens, B, L, enc_out, sc, st));
+  NS_TRY(predictor(m, m->pred[0], enc_out, lens, B, L, 1.0f, nullptr, log_d, nullptr, nullptr, nullptr, nullptr, sc, st));
+  NS_HIP(launch_duration_round(log_d, B * L, d_control, d_rounded, st));
+  NS_HIP(launch_duration_scan(d_rounded, B, L, cum, (long long*)mel_lens, st));
+  return 0;
+}
+
+extern "C" int ns_forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens, float p_control, float e_control,
+                              const float* p_targets, const float* e_targets,
+                              const void* ws_enc, void* ws_dec, size_t ws_bytes, float* mel, float* postnet_mel, float* p_pred,
+                              float* e_pred, uint8_t* mel_mask, void* stream) {
+  NS_TRY(check_ready(m));
+  if (B <= 0 || L <= 0) return fail("ns_forward_mel: empty batch");
+  if (T <= 0) return 0;  // all durations zero: [B,0,*] outputs, nothing to launch
+  if (ws_bytes < ns_decoder_ws_bytes(m, B, L, T)) return fail("ns_forward_mel: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const ns_config& c = m->cfg;
+  Bump be(const_cast<void*>(ws_enc), (size_t)-1);
+  const float* enc_out = be.f((size_t)B * L * c.d_enc);
+  const int32_t* cum = (const int32_t*)be.raw((size_t)B * L * sizeof(int32_t));
+  Bump bp(ws_dec, ws_bytes);
+  Scratch sc = carve(c, bp, (size_t)B * T, T);
+  const long long* lens = (const long long*)mel_lens;
+  const int d = c.d_dec, M = B * T;
+
+  NS_HIP(launch_mask_from_lengths(lens, B, T, mel_mask, st));
+  NS_HIP(launch_length_regulate(enc_out, cum, B, L, c.d_enc, T, sc.xa, st));
+  const float* pos;
+  NS_TRY(position_rows(m, m->dec_pos, T, d, sc, &pos, st));
+  // frame-level pitch then energy (model/modules.py:139-149); the decoder's position add rides on the second one
+  NS_TRY(predictor(m, m->pred[1], sc.xa, lens, B, T, p_control, p_targets, p_pred, m->P(m->pitch_bins), m->P(m->pitch_emb), nullptr,
+                   sc.xb, sc, st));
+  NS_TRY(predictor(m, m->pred[2], sc.xb, lens, B, T, e_control, e_targets, e_pred, m->P(m->energy_bins), m->P(m->energy_emb), pos,
+                   sc.xa, sc, st));
+  NS_TRY(decoder_stack(m, sc.xa, lens, B, T, sc.att, sc, st));
+  // note: decoder_stack's last layer writes into sc.att only after its own attention output was consumed
+  NS_TRY(gemm(sc.att, d, m->P(m->mel_w), m->P(m->mel_b), nullptr, 0, mel, c.n_mel, M, c.n_mel, d, 1, T, ACT_NONE, st));
+  NS_TRY(postnet(m, mel, B, T, mel, postnet_mel, sc, st));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- per-op entry points
+static int find_layer(ns_model* m, const char* prefix_c, const LayerW** L, int* d, int* H, const char* suffix) {
+  std::string p(prefix_c ? prefix_c : "");
+  if (suffix && *suffix) {
+    if (!ends_with(p, suffix)) return fail("prefix '" + p + "' does not end with '" + suffix + "'");
+    p.resize(p.size() - strlen(suffix));
+  }
+  const bool enc = starts_with(p, "txt_encoder.layer_stack."), dec = starts_with(p, "mel_decoder.layer_stack.");
+  if (!enc && !dec) return fail("unknown module prefix '" + std::string(prefix_c ? prefix_c : "") + "'");
+  const int idx = atoi(p.c_str() + (enc ? strlen("txt_encoder.layer_stack.") : strlen("mel_decoder.layer_stack.")));
+  auto& v = enc ? m->enc : m->dec;
+  if (idx < 0 || idx >= (int)v.size()) return fail("layer index out of range in '" + p + "'");
+  *L = &v[idx];
+  *d = enc ? m->cfg.d_enc : m->cfg.d_dec;
+  *H = enc ? m->cfg.n_enc_head : m->cfg.n_dec_head;
+  return 0;
+}
+
+#define NS_OP_PROLOGUE(B_, S_)                                                        \
+  NS_TRY(check_ready(m));                                                             \
+  if ((B_) <= 0 || (S_) <= 0) return fail("empty input");                             \
+  if (ws_bytes < ns_op_ws_bytes(m, (B_), (S_))) return fail("workspace too small");   \
+  hipStream_t st = (hipStream_t)stream;                                               \
+  Bump bp(ws, ws_bytes);                                                              \
+  Scratch sc = carve(m->cfg, bp, (size_t)(B_) * (S_), (S_));
+
+extern "C" int ns_op_mask_from_lengths(const int64_t* lens, int B, int max_len, uint8_t* mask, void* stream) {
+  NS_HIP(launch_mask_from_lengths((const long long*)lens, B, max_len, mask, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ns_op_sinusoid_table(int n_position, int d_hid, float* out, void* stream) {
+  NS_HIP(launch_sinusoid(n_position, d_hid, out, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ns_op_txt_encoder(ns_model* m, const int64_t* texts, const int64_t* lens, int B, int L, float* out, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  NS_OP_PROLOGUE(B, L);
+  return encoder(m, (const long long*)texts, (const long long*)lens, B, L, out, sc, st);
+}
+extern "C" int ns_op_multi_head_attention(ns_model* m, const char* prefix, const float* x, const int64_t* lens, int B, int S,
+                                          float* out, void* ws, size_t ws_bytes, void* stream) {
+  NS_OP_PROLOGUE(B, S);
+  const LayerW* L; int d, H;
+  NS_TRY(find_layer(m, prefix, &L, &d, &H, ".slf_attn"));
+  return mha(m, *L, d, H, x, (const long long*)lens, B, S, out, false, sc, st);
+}
+extern "C" int ns_op_positionwise_ffn(ns_model* m, const char* prefix, const float* x, int B, int S, float* out, void* ws,
+                                      size_t ws_bytes, void* stream) {
+  NS_OP_PROLOGUE(B, S);
+  const LayerW* L; int d, H;
+  NS_TRY(find_layer(m, prefix, &L, &d, &H, ".pos_ffn"));
+  return ffn(m, *L, d, x, nullptr, B, S, out, false, sc, st);
+}
+extern "C" int ns_op_fft_block(ns_model* m, const char* prefix, const float* x, const int64_t* lens, int B, int S, float* out,
+                               void* ws, size_t ws_bytes, void* stream) {
+  NS_OP_PROLOGUE(B, S);
+  const LayerW* L; int d, H;
+  NS_TRY(find_layer(m, prefix, &L, &d, &H, ""));
+  return fft_block(m, *L, d, H, x, (const long long*)lens, B, S, out, sc, st);
+}
+static int find_pred(const char* prefix, int* idx) {
+  std::string p(prefix ? prefix : "");
+  for (int i = 0; i < 3; ++i)
+    if (p == std::string("variance_adaptor.") + kPredNames[i] + "_predictor") { *idx = i; return 0; }
+  return fail("unknown predictor prefix '" + p + "'");
+}
+extern "C" int ns_op_variance_predictor(ns_model* m, const char* prefix, const float* x, const int64_t* lens, int B, int S,
+                                        float* out, void* ws, size_t ws_bytes, void* stream) {
+  NS_OP_PROLOGUE(B, S);
+  int i;
+  NS_TRY(find_pred(prefix, &i));
+  return predictor(m, m->pred[i], x, (const long long*)lens, B, S, 1.0f, nullptr, out, nullptr, nullptr, nullptr, nullptr, sc, st);
+}
+extern "C" int ns_op_duration_round(const float* log_d, int n, float d_control, float* d_rounded, void* stream) {
+  NS_HIP(launch_duration_round(log_d, n, d_control, d_rounded, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ns_op_duration_scan(const float* d_rounded, int B, int L, int32_t* cum, int64_t* mel_lens, void* stream) {
+  NS_HIP(launch_duration_scan(d_rounded, B, L, cum, (long long*)mel_lens, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ns_op_length_regulate(const float* x, const int32_t* cum, int B, int L, int D, int T, float* out, void* stream) {
+  NS_HIP(launch_length_regulate(x, cum, B, L, D, T, out, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ns_op_variance_embedding(ns_model* m, int which, const float* x, const int64_t* lens, int B, int S, float control,
+                                        const float* target, float* pred, float* x_out, void* ws, size_t ws_bytes, void* stream) {
+  NS_OP_PROLOGUE(B, S);
+  if (which != 0 && which != 1) return fail("which must be 0 (pitch) or 1 (energy)");
+  const size_t bins = which ? m->energy_bins : m->pitch_bins, emb = which ? m->energy_emb : m->pitch_emb;
+  return predictor(m, m->pred[1 + which], x, (const long long*)lens, B, S, control, target, pred, m->P(bins), m->P(emb), nullptr, x_out,
+                   sc, st);
+}
+extern "C" int ns_profile_enable(ns_model* m, int on) {
+  if (!m) return fail("ns_profile_enable: null model");
+  m->prof = on != 0;
+  m->prof_used = 0;
+  m->prof_flops = 0.0;
+  return 0;
+}
+extern "C" int ns_profile_read(ns_model* m, double* total_ms, double* total_flops, int64_t* launches) {
+  if (!m) return fail("ns_profile_read: null model");
+  double ms = 0.0;
+  for (size_t i = 0; i < m->prof_used; ++i) {
+    NS_HIP(hipEventSynchronize(m->prof_ev[i].second));
+    float e = 0.f;
+    NS_HIP(hipEventElapsedTime(&e, m->prof_ev[i].first, m->prof_ev[i].second));
+    ms += e;
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = m->prof_flops;
+  if (launches) *launches = (int64_t)m->prof_used;
+  m->prof_used = 0;
+  m->prof_flops = 0.0;
+  return 0;
+}
+extern "C" int ns_op_bucketize(const float* values, int n, const float* bins, int n_edges, int64_t* idx, void* stream) {
+  NS_HIP(launch_bucketize(values, n, bins, n_edges, (long long*)idx, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ns_op_gaussian_upsampling(const float* x, const float* durations, int B, int L, int D, int T, int T_out, float* out,
+                                         float* s, float* w, void* stream) {
+  if (T_out < T) return fail("ns_op_gaussian_upsampling: T_out < T");
+  if ((size_t)L * sizeof(float) > 60000) return fail("ns_op_gaussian_upsampling: L too large");
+  NS_HIP(launch_gaussian_upsampling(x, durations, B, L, D, T, T_out, out, s, w, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ns_op_mel_decoder(ns_model* m, const float* x, const int64_t* lens, int B, int T, float* out, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  NS_OP_PROLOGUE(B, T);
+  const float* pos;
+  NS_TRY(position_rows(m, m->dec_pos, T, m->cfg.d_dec, sc, &pos, st));
+  NS_HIP(launch_add_pos(x, pos, sc.xa, B * T, T, m->cfg.d_dec, st));
+  return decoder_stack(m, sc.xa, (const long long*)lens, B, T, out, sc, st);
+}
+extern "C" int ns_op_mel_linear(ns_model* m, const float* x, int B, int T, float* out, void* stream) {
+  NS_TRY(check_ready(m));
+  const ns_config& c = m->cfg;
+  return gemm(x, c.d_dec, m->P(m->mel_w), m->P(m->mel_b), nullptr, 0, out, c.n_mel, B * T, c.n_mel, c.d_dec, 1, T, ACT_NONE,
+              (hipStream_t)stream);
+}
+extern "C" int ns_op_postnet(ns_model* m, const float* mel, int B, int T, float* out, void* ws, size_t ws_bytes, void* stream) {
+  NS_OP_PROLOGUE(B, T);
+  return postnet(m, mel, B, T, nullptr, out, sc, st);
+}
+extern "C" int ns_op_ffn_conv1(ns_model* m, const char* prefix, const float* x, int B, int S, float* hidden, void* stream) {
+  NS_TRY(check_ready(m));
+  const LayerW* L; int d, H;
+  NS_TRY(find_layer(m, prefix, &L, &d, &H, ".pos_ffn"));
+  const ns_config& c = m->cfg;
+  return gemm(x, d, m->P(L->w1), m->P(L->w1_b), nullptr, 0, hidden, c.d_inner, B * S, c.d_inner, d, c.ffn_k1, S, ACT_RELU,
+              (hipStream_t)stream);
+}

@@ -1,0 +1,52 @@
+// Internal launch interface between the C-ABI (api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ns {
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+
+// Y[m, n] = act( sum_{j<KW} sum_{c<Cin} X[m + j - pad, c] * W[n][j*Cin + c] + bias[n] ) + resid[m, n]
+// rows of X outside the utterance's [0, S) window read as zero ("same" zero padding of nn.Conv1d);
+// rows whose position t = m % S is >= lens[m / S] are written as zero when lens != nullptr.
+struct ConvGemm {
+  const float* X; int ldx;
+  const float* W;               // packed [N][KW*Cin]
+  const float* bias;            // [N] or nullptr
+  const float* resid; int ldr;  // [M, N] or nullptr
+  float* Y; int ldy;
+  const long long* lens;        // [M / S] or nullptr
+  int M, N, Cin, KW, pad, S;
+  int act;
+};
+hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st);
+
+// Fused multi-head self attention over the packed projection buffer qkv [B*S, 3*d]
+// (cols [0,d) = Q, [d,2d) = K, [2d,3d) = V, head h at offset h*dk inside each).
+// out [B*S, d] = merge_heads( softmax(Q K^T / sqrt(dk) + (-inf at keys >= lens[b])) V )
+hipError_t launch_attention(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, hipStream_t st);
+
+// ---- row kernels (rowops.hip) -----------------------------------------------------------------
+// y = LayerNorm_C(x) * g + b ; rows with t >= lens[b] are written as zero when lens != nullptr
+hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, int C, int S,
+                            const long long* lens, hipStream_t st);
+// pred[m] = mask ? 0 : dot(LayerNorm_C(x[m]), wlin) + blin            (variance predictor tail)
+// if emb != nullptr additionally  x_out[m,:] = x_in[m,:] + emb[bucketize(pred[m]*control, bins)] (+ pos[t,:])
+hipError_t launch_ln_linear_embed(const float* x, const float* g, const float* b, const float* wlin, const float* blin,
+                                  float* pred, int M, int C, int S, const long long* lens, float control,
+                                  const float* target, const float* bins, int n_bins, const float* emb, const float* x_in, const float* pos,
+                                  float* x_out, int D, hipStream_t st);
+// out[m,:] = emb[texts[m],:] + pos[t,:]
+hipError_t launch_embed_pos(const long long* texts, const float* emb, const float* pos, float* out, int M, int S, int D, hipStream_t st);
+hipError_t launch_add_pos(const float* x, const float* pos, float* out, int M, int S, int D, hipStream_t st);
+hipError_t launch_bucketize(const float* v, int n, const float* bins, int n_edges, long long* idx, hipStream_t st);
+hipError_t launch_mask_from_lengths(const long long* lens, int B, int max_len, uint8_t* mask, hipStream_t st);
+hipError_t launch_sinusoid(int n_pos, int d, float* out, hipStream_t st);
+hipError_t launch_duration_round(const float* log_d, int n, float d_control, float* d_rounded, hipStream_t st);
+hipError_t launch_duration_scan(const float* d_rounded, int B, int L, int32_t* cum, long long* mel_lens, hipStream_t st);
+hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int L, int D, int T, float* out, hipStream_t st);
+hipError_t launch_gaussian_upsampling(const float* x, const float* dur, int B, int L, int D, int T, int T_out,
+                                      float* out, float* s, float* w, hipStream_t st);
+
+}  // namespace ns

@@ -1,0 +1,392 @@
+// Row-wise (HBM-bound) kernels of the path: one wave64 per activation row, float4 (16 B/lane) accesses,
+// wavefront shuffles for the reductions.  Each one cites the reference lines it restates.
+#include "kernels.h"
+
+namespace ns {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+constexpr float LN_EPS = 1e-5f;  // torch.nn.LayerNorm default
+
+// torch.bucketize(v, bins, right=False) (model/modules.py:86-88,97-99), wave-cooperative: the index is the number
+// of edges e with !(e >= v) — for sorted edges that is the first i with bins[i] >= v, and NaN maps to n_edges.
+__device__ __forceinline__ int wave_bucketize(const float* __restrict__ bins, int n_edges, float v, int lane) {
+  int cnt = 0;
+  for (int k = lane; k < n_edges; k += 64) cnt += !(bins[k] >= v) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  return cnt;
+}
+
+// Loads row `x` (C floats, C % 4 == 0, C <= 1024) as up to NV float4 per lane and returns mean / rstd.
+template <int NV>
+__device__ __forceinline__ void ln_stats(const float* x, int C, int lane, f32x4 (&v)[NV], float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < C) v[i] = *reinterpret_cast<const f32x4*>(x + c);
+    else v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dlt = v[i][e] - mean;
+        q += dlt * dlt;
+      }
+    }
+  }
+  const float var = wave_sum(q) / (float)C;  // biased variance, as nn.LayerNorm
+  rstd = 1.0f / sqrtf(var + LN_EPS);
+}
+
+// y = LN(x)*g + b ; rows at t >= lens[b] -> 0.  Covers `layer_norm(output + residual)` followed by
+// FFTBlock's masked_fill (transformer/SubLayers.py:57,93 + transformer/Layers.py:43,46) — the residual add is
+// done by the producing GEMM's epilogue — and the predictors' layer_norm_1 (model/modules.py:260).
+template <int NV>
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ g,
+                                                    const float* __restrict__ bta, float* __restrict__ y, int M, int C,
+                                                    int S, const long long* __restrict__ lens) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  f32x4 v[NV];
+  float mean, rstd;
+  ln_stats<NV>(x + (size_t)m * C, C, lane, v, mean, rstd);
+  bool pad = false;
+  if (lens) pad = (long long)(m % S) >= lens[m / S];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < C) {
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(bta + c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pad ? 0.f : (v[i][e] - mean) * rstd * gg[e] + bb[e];
+      *reinterpret_cast<f32x4*>(y + (size_t)m * C + c) = o;
+    }
+  }
+}
+
+hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, int C, int S,
+                            const long long* lens, hipStream_t st) {
+  if (M <= 0) return hipSuccess;
+  if (C % 4 != 0 || C > 1024) return hipErrorInvalidValue;
+  dim3 grid((M + 3) / 4), block(256);
+  if (C <= 256) hipLaunchKernelGGL((k_layernorm<1>), grid, block, 0, st, x, g, b, y, M, C, S, lens);
+  else if (C <= 512) hipLaunchKernelGGL((k_layernorm<2>), grid, block, 0, st, x, g, b, y, M, C, S, lens);
+  else hipLaunchKernelGGL((k_layernorm<4>), grid, block, 0, st, x, g, b, y, M, C, S, lens);
+  return hipGetLastError();
+}
+
+// Tail of VariancePredictor.forward (model/modules.py:273-286): layer_norm_2 -> Linear(F->1) -> squeeze ->
+// masked_fill(mask, 0).  Optionally fused with get_pitch_embedding / get_energy_embedding and the UNMASKED
+// residual add of VarianceAdaptor.forward (model/modules.py:80-100,139-149):
+//   idx = bucketize(pred*control, bins)  (right=False: number of bin edges e with !(e >= v); NaN -> n_bins-1)
+//   x_out[m,:] = x_in[m,:] + emb[idx,:]  (+ pos[t,:]: MelDecoder's position add, transformer/Models.py:222,231)
+template <int NV>
+__global__ __launch_bounds__(256) void k_ln_linear_embed(const float* __restrict__ x, const float* __restrict__ g,
+                                                          const float* __restrict__ bta, const float* __restrict__ wlin,
+                                                          const float* __restrict__ blin, float* __restrict__ pred, int M,
+                                                          int C, int S, const long long* __restrict__ lens, float control,
+                                                          const float* __restrict__ target,
+                                                          const float* __restrict__ bins, int n_edges,
+                                                          const float* __restrict__ emb, const float* __restrict__ x_in,
+                                                          const float* __restrict__ pos, float* __restrict__ x_out, int D) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  f32x4 v[NV];
+  float mean, rstd;
+  ln_stats<NV>(x + (size_t)m * C, C, lane, v, mean, rstd);
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < C) {
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(bta + c);
+      const f32x4 ww = *reinterpret_cast<const f32x4*>(wlin + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dot += ((v[i][e] - mean) * rstd * gg[e] + bb[e]) * ww[e];
+    }
+  }
+  const int t = m % S;
+  float pv = wave_sum(dot) + blin[0];
+  if (lens && (long long)t >= lens[m / S]) pv = 0.f;
+  // model/modules.py:82-89: with a target the embedding comes from bucketize(target) and the prediction is returned
+  // unscaled; without one prediction = prediction * control and the embedding comes from the scaled prediction
+  if (target == nullptr) pv *= control;
+  if (lane == 0) pred[m] = pv;
+  if (emb == nullptr) return;
+  const int cnt = wave_bucketize(bins, n_edges, target ? target[m] : pv, lane);
+  const float* er = emb + (size_t)cnt * D;
+  for (int c = lane * 4; c < D; c += 256) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(x_in + (size_t)m * D + c);
+    const f32x4 e4 = *reinterpret_cast<const f32x4*>(er + c);
+    a += e4;
+    if (pos) a += *reinterpret_cast<const f32x4*>(pos + (size_t)t * D + c);
+    *reinterpret_cast<f32x4*>(x_out + (size_t)m * D + c) = a;
+  }
+}
+
+hipError_t launch_ln_linear_embed(const float* x, const float* g, const float* b, const float* wlin, const float* blin,
+                                  float* pred, int M, int C, int S, const long long* lens, float control,
+                                  const float* target, const float* bins, int n_bins, const float* emb, const float* x_in, const float* pos,
+                                  float* x_out, int D, hipStream_t st) {
+  if (M <= 0) return hipSuccess;
+  if (C % 4 != 0 || C > 1024 || (emb && D % 4 != 0)) return hipErrorInvalidValue;
+  dim3 grid((M + 3) / 4), block(256);
+  const int n_edges = n_bins - 1;
+#define NS_ARGS x, g, b, wlin, blin, pred, M, C, S, lens, control, target, bins, n_edges, emb, x_in, pos, x_out, D
+  if (C <= 256) hipLaunchKernelGGL((k_ln_linear_embed<1>), grid, block, 0, st, NS_ARGS);
+  else if (C <= 512) hipLaunchKernelGGL((k_ln_linear_embed<2>), grid, block, 0, st, NS_ARGS);
+  else hipLaunchKernelGGL((k_ln_linear_embed<4>), grid, block, 0, st, NS_ARGS);
+#undef NS_ARGS
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_bucketize(const float* __restrict__ v, int n, const float* __restrict__ bins,
+                                                    int n_edges, long long* __restrict__ idx) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int c = wave_bucketize(bins, n_edges, v[i], lane);
+  if (lane == 0) idx[i] = c;
+}
+hipError_t launch_bucketize(const float* v, int n, const float* bins, int n_edges, long long* idx, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_bucketize, dim3((n + 3) / 4), dim3(256), 0, st, v, n, bins, n_edges, idx);
+  return hipGetLastError();
+}
+
+// TxtEncoder.forward input: src_word_emb(src_seq) + position_enc[:, :L] (transformer/Models.py:82-91).
+__global__ __launch_bounds__(256) void k_embed_pos(const long long* __restrict__ texts, const float* __restrict__ emb,
+                                                    const float* __restrict__ pos, float* __restrict__ out, int M, int S, int D) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const long long tok = texts[m];
+  const int t = m % S;
+  for (int c = lane * 4; c < D; c += 256) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(emb + (size_t)tok * D + c);
+    a += *reinterpret_cast<const f32x4*>(pos + (size_t)t * D + c);
+    *reinterpret_cast<f32x4*>(out + (size_t)m * D + c) = a;
+  }
+}
+hipError_t launch_embed_pos(const long long* texts, const float* emb, const float* pos, float* out, int M, int S, int D, hipStream_t st) {
+  if (M <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_embed_pos, dim3((M + 3) / 4), dim3(256), 0, st, texts, emb, pos, out, M, S, D);
+  return hipGetLastError();
+}
+
+// MelDecoder.forward input: enc_seq + position table (transformer/Models.py:218-235).
+__global__ __launch_bounds__(256) void k_add_pos(const float* __restrict__ x, const float* __restrict__ pos,
+                                                  float* __restrict__ out, int M, int S, int D) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int t = m % S;
+  for (int c = lane * 4; c < D; c += 256) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)m * D + c);
+    a += *reinterpret_cast<const f32x4*>(pos + (size_t)t * D + c);
+    *reinterpret_cast<f32x4*>(out + (size_t)m * D + c) = a;
+  }
+}
+hipError_t launch_add_pos(const float* x, const float* pos, float* out, int M, int S, int D, hipStream_t st) {
+  if (M <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_add_pos, dim3((M + 3) / 4), dim3(256), 0, st, x, pos, out, M, S, D);
+  return hipGetLastError();
+}
+
+// get_mask_from_lengths (utils/tools.py:89-97): mask[b,t] = t >= lens[b]; 1 = padding.
+__global__ void k_mask(const long long* __restrict__ lens, int B, int max_len, uint8_t* __restrict__ mask) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * max_len) return;
+  const int b = (int)(i / max_len), t = (int)(i % max_len);
+  mask[i] = (long long)t >= lens[b] ? 1 : 0;
+}
+hipError_t launch_mask_from_lengths(const long long* lens, int B, int max_len, uint8_t* mask, hipStream_t st) {
+  const long long n = (long long)B * max_len;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lens, B, max_len, mask);
+  return hipGetLastError();
+}
+
+// get_sinusoid_encoding_table (transformer/Models.py:10-30): the angle and sin/cos are evaluated in float64
+// and only then cast to float32, exactly as numpy does in the reference.
+__global__ void k_sinusoid(int n_pos, int d, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)n_pos * d) return;
+  const int p = (int)(i / d), j = (int)(i % d);
+  const double ang = (double)p / pow(10000.0, (double)(2 * (j / 2)) / (double)d);
+  out[i] = (float)((j & 1) ? cos(ang) : sin(ang));
+}
+hipError_t launch_sinusoid(int n_pos, int d, float* out, hipStream_t st) {
+  const long long n = (long long)n_pos * d;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_sinusoid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n_pos, d, out);
+  return hipGetLastError();
+}
+
+// duration_rounded = clamp(round(exp(log_d) - 1) * d_control, min=0) (model/modules.py:132-135).
+// torch.round is round-half-to-even -> rintf; the clamp keeps -0.0 and NaN like torch.clamp does.
+__global__ void k_duration_round(const float* __restrict__ log_d, int n, float d_control, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float r = rintf(expf(log_d[i]) - 1.0f) * d_control;
+  out[i] = (r < 0.f) ? 0.f : r;
+}
+hipError_t launch_duration_round(const float* log_d, int n, float d_control, float* d_rounded, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_duration_round, dim3((n + 255) / 256), dim3(256), 0, st, log_d, n, d_control, d_rounded);
+  return hipGetLastError();
+}
+
+// LengthRegulator.expand's repeat counts (model/modules.py:221-223): max(int(d), 0), int() truncating toward
+// zero, and their inclusive prefix sums; mel_len[b] = total (model/modules.py:209-211).  One workgroup per utterance.
+__global__ __launch_bounds__(256) void k_duration_scan(const float* __restrict__ d, int L, int32_t* __restrict__ cum,
+                                                        long long* __restrict__ mel_lens) {
+  __shared__ int wsum[4];
+  __shared__ int carry_s;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int l0 = 0; l0 < L; l0 += 256) {
+    const int l = l0 + tid;
+    int v = 0;
+    if (l < L) {
+      const int r = (int)d[(size_t)b * L + l];
+      v = r > 0 ? r : 0;
+    }
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int n = __shfl_up(inc, o);
+      if (lane >= o) inc += n;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    int off = carry_s;
+    for (int w = 0; w < wid; ++w) off += wsum[w];
+    if (l < L) cum[(size_t)b * L + l] = inc + off;
+    __syncthreads();
+    if (tid == 255) carry_s = inc + off;
+    __syncthreads();
+  }
+  if (tid == 0) mel_lens[b] = (long long)carry_s;
+}
+hipError_t launch_duration_scan(const float* d_rounded, int B, int L, int32_t* cum, long long* mel_lens, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_duration_scan, dim3(B), dim3(256), 0, st, d_rounded, L, cum, mel_lens);
+  return hipGetLastError();
+}
+
+// LengthRegulator.LR + pad (model/modules.py:201-218, utils/tools.py:288-306) as a gather: output frame t of
+// utterance b copies encoder row i = first index with cum[b][i] > t; frames at t >= mel_len[b] are zero.
+__global__ __launch_bounds__(256) void k_length_regulate(const float* __restrict__ x, const int32_t* __restrict__ cum, int L,
+                                                          int D, int T, int M, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int b = m / T, t = m % T;
+  const int32_t* cb = cum + (size_t)b * L;
+  const int total = L > 0 ? cb[L - 1] : 0;
+  float* dst = out + (size_t)m * D;
+  if (t >= total) {
+    for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<f32x4*>(dst + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+  int lo = 0, hi = L - 1;  // smallest i with cb[i] > t
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (cb[mid] > t) hi = mid;
+    else lo = mid + 1;
+  }
+  const float* src = x + ((size_t)b * L + lo) * D;
+  for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(src + c);
+}
+hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int L, int D, int T, float* out, hipStream_t st) {
+  const int M = B * T;
+  if (M <= 0) return hipSuccess;
+  if (D % 4 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_length_regulate, dim3((M + 3) / 4), dim3(256), 0, st, x, cum, L, D, T, M, out);
+  return hipGetLastError();
+}
+
+// GaussianUpsampling.forward (model/modules.py:166-192; defined but never called by the reference forward,
+// SURVEY.md F1).  c = cumsum(d) - d/2 ; w[b,l,t] = exp(-0.01 (t-c)^2) / (sum_l exp(..) + 1e-20) ; out = w^T x.
+// t spans [0, T) with T = max_b sum(d): rows past an utterance's own length are NOT zeroed; rows in
+// [T, T_out) are the zero padding of pad(output, max_len).  One workgroup per output frame.
+__global__ __launch_bounds__(256) void k_gauss_centers(const float* __restrict__ dur, int L, float* __restrict__ centers,
+                                                        float* __restrict__ s) {
+  // sequential fp32 cumsum per utterance, as torch.cumsum on CPU accumulates
+  const int b = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  float e = 0.f;
+  for (int l = 0; l < L; ++l) {
+    const float dl = dur[(size_t)b * L + l];
+    e += dl;
+    centers[(size_t)b * L + l] = e - 0.5f * dl;
+  }
+  s[b] = e;
+}
+__global__ __launch_bounds__(256) void k_gauss_upsample(const float* __restrict__ x, const float* __restrict__ centers, int L,
+                                                         int D, int T, int T_out, float* __restrict__ out,
+                                                         float* __restrict__ w) {
+  extern __shared__ float wl[];  // [L]
+  __shared__ float red[4];
+  const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float* orow = out + ((size_t)b * T_out + t) * D;
+  if (t >= T) {
+    for (int c = tid; c < D; c += 256) orow[c] = 0.f;
+    return;
+  }
+  float part = 0.f;
+  for (int l = tid; l < L; l += 256) {
+    const float df = (float)t - centers[(size_t)b * L + l];
+    const float e = expf(-0.01f * (df * df));
+    wl[l] = e;
+    part += e;
+  }
+  part = wave_sum(part);
+  if (lane == 0) red[wid] = part;
+  __syncthreads();
+  const float w2 = ((red[0] + red[1]) + (red[2] + red[3])) + 1e-20f;
+  for (int l = tid; l < L; l += 256) {
+    const float wv = wl[l] / w2;
+    wl[l] = wv;
+    if (w) w[((size_t)b * L + l) * T + t] = wv;
+  }
+  __syncthreads();
+  for (int c = tid; c < D; c += 256) {
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) acc = fmaf(wl[l], x[((size_t)b * L + l) * D + c], acc);
+    orow[c] = acc;
+  }
+}
+hipError_t launch_gaussian_upsampling(const float* x, const float* dur, int B, int L, int D, int T, int T_out, float* out,
+                                      float* s, float* w, hipStream_t st) {
+  if (B <= 0 || T_out <= 0) return hipSuccess;
+  // centers are staged in the head of `out`'s tail? no: use the w buffer's caller-provided scratch is not available,
+  // so centers live in a small device-side region carved from `s`: s must have room for B + B*L floats.
+  float* centers = s + B;
+  hipLaunchKernelGGL(k_gauss_centers, dim3(B), dim3(64), 0, st, dur, L, centers, s);
+  hipLaunchKernelGGL(k_gauss_upsample, dim3(T_out, B), dim3(256), L * sizeof(float), st, x, centers, L, D, T, T_out, out, w);
+  return hipGetLastError();
+}
+
+}  // namespace ns

@@ -1,0 +1,241 @@
+"""Drop-in for the reference's ``model.FastSpeech2Align`` on the inference path.
+
+Same constructor arguments, ``forward()`` signature, 12-tuple return and
+``state_dict`` key names as ``model/fastspeech2_align.py:13-100`` so that
+``synthesize.py:59-76`` (``model(*(batch[2:]))`` under ``torch.no_grad()``) runs
+unchanged.  All tensor math happens in the HIP kernels behind the C-ABI
+(``include/nar_fs2.h``); PyTorch is the allocator and stream owner only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import workload as wl
+
+
+def config_struct(preprocess_config: dict, model_config: dict) -> _lib.NsConfig:
+    """The keys ``FastSpeech2Align.__init__`` reads (model/fastspeech2_align.py:16-28,
+    model/modules.py:20-77, transformer/Models.py:36-71,176-210) as the C-ABI's ns_config."""
+    t = model_config["transformer"]
+    vp = model_config["variance_predictor"]
+    pp = preprocess_config["preprocessing"]
+    for lvl in (pp["pitch"]["feature"], pp["energy"]["feature"]):
+        assert lvl in ["phoneme_level", "frame_level"]  # model/modules.py:32-33
+    ks = t["conv_kernel_size"]
+    return _lib.NsConfig(
+        n_vocab=wl.N_SYMBOLS + 1, max_seq_len=model_config["max_seq_len"],
+        d_enc=t["encoder_hidden"], n_enc_layer=t["encoder_layer"], n_enc_head=t["encoder_head"],
+        d_dec=t["decoder_hidden"], n_dec_layer=t["decoder_layer"], n_dec_head=t["decoder_head"],
+        d_inner=t["conv_filter_size"], ffn_k1=ks[0], ffn_k2=ks[1],
+        vp_filter=vp["filter_size"], vp_kernel=vp["kernel_size"],
+        n_bins=model_config["variance_embedding"]["n_bins"], n_mel=pp["mel"]["n_mel_channels"],
+        postnet_dim=wl.POSTNET_DIM, postnet_k=wl.POSTNET_K, postnet_n=wl.POSTNET_N,
+        pitch_frame_level=int(pp["pitch"]["feature"] == "frame_level"),
+        energy_frame_level=int(pp["energy"]["feature"] == "frame_level"),
+    )
+
+
+class FastSpeech2Align:
+    """FastSpeech2 (inference) — HIP/gfx950 implementation of the reference module of the same name."""
+
+    def __init__(self, preprocess_config: dict, model_config: dict):
+        self.model_config = model_config
+        self.preprocess_config = preprocess_config
+        self._lib = _lib.load()
+        self._cfg = config_struct(preprocess_config, model_config)
+        h = C.c_void_p()
+        _lib.check(self._lib.ns_create(C.byref(self._cfg), C.byref(h)), "ns_create")
+        self._h = h
+        self._device = None
+        self._arena = None
+        self._ws = {}
+        self._sd = OrderedDict()  # host copy of what load_state_dict received (for state_dict() / .to())
+        self.training = False
+        # VarianceAdaptor.__init__ opens stats.json for the bin edges (model/modules.py:41-71); they are
+        # also state-dict entries, so a checkpoint overrides them.
+        sp = os.path.join(preprocess_config["path"]["preprocessed_path"], "stats.json")
+        if os.path.exists(sp):
+            with open(sp) as f:
+                stats = json.load(f)
+            pb, eb = wl.variance_bins(model_config, stats)
+            self._sd["variance_adaptor.pitch_bins"] = pb
+            self._sd["variance_adaptor.energy_bins"] = eb
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.ns_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- nn.Module-shaped surface ------------------------------------------------------------
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("training is out of scope for this path (SURVEY.md §2); only eval() is supported")
+        return self.eval()
+
+    def requires_grad_(self, flag: bool = False):
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("this implementation runs on an MI355X only (device must be 'cuda[:N]'); there is no CPU path")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if self._device != device:
+            self._device = device
+            self._arena = None
+            self._ws = {}
+            if self._sd:
+                self._upload()
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    def state_dict(self):
+        return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in self._sd.items())
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Accepts the reference's checkpoint["model"] (utils/model.py:21-22).  ``mel_encoder.*`` (training-only
+        aligner) and ``num_batches_tracked`` entries are accepted and ignored."""
+        for k, v in state_dict.items():
+            a = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+            if k.startswith("mel_encoder.") or k.endswith("num_batches_tracked"):
+                continue
+            self._sd[k] = np.ascontiguousarray(a, dtype=np.float32)
+        if self._device is None and torch.cuda.is_available():
+            self._device = torch.device("cuda", torch.cuda.current_device())
+        if self._device is not None:
+            self._upload()
+        return [], []
+
+    def _bind_arena(self):
+        nbytes = self._lib.ns_arena_bytes(self._h)
+        with torch.cuda.device(self._device):
+            self._arena = torch.empty(nbytes, dtype=torch.uint8, device=self._device)
+            _lib.check(self._lib.ns_bind_arena(self._h, _lib.ptr(self._arena), nbytes), "ns_bind_arena")
+
+    def _upload(self):
+        if self._arena is None:
+            self._bind_arena()
+        with torch.cuda.device(self._device):
+            for k, a in self._sd.items():
+                shape = (C.c_int64 * a.ndim)(*a.shape)
+                _lib.check(self._lib.ns_set_weight(self._h, k.encode(), C.c_void_p(a.ctypes.data), shape, a.ndim),
+                           "load_state_dict")
+            _lib.check(self._lib.ns_finalize_weights(self._h, _lib.stream_ptr(self._device)), "load_state_dict")
+
+    # ---- multi-GPU weight replication: rank 0 packs, everyone else adopts the bytes ----
+    def arena_tensor(self) -> torch.Tensor:
+        if self._arena is None:
+            if self._device is None:
+                self._device = torch.device("cuda", torch.cuda.current_device())
+            self._bind_arena()
+        return self._arena
+
+    def adopt_arena(self):
+        _lib.check(self._lib.ns_adopt_arena(self._h), "ns_adopt_arena")
+
+    # ---- measurement hook (bench.py roofline leg) ----------------------------------------------------
+    def profile_dominant_kernel(self, on: bool = True):
+        _lib.check(self._lib.ns_profile_enable(self._h, int(on)), "ns_profile_enable")
+
+    def read_profile(self):
+        """(total kernel ms, total algorithmic flops, launches) of the FFN k=9 Conv1D-as-GEMM since the last read."""
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+        _lib.check(self._lib.ns_profile_read(self._h, C.byref(ms), C.byref(fl), C.byref(n)), "ns_profile_read")
+        return ms.value, fl.value, n.value
+
+    # ---- forward -------------------------------------------------------------------------------
+    def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
+        w = self._ws.get(key)
+        if w is None or w.numel() < nbytes:
+            w = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self._device)
+            self._ws[key] = w
+        return w
+
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
+
+    def forward(self, speakers, texts, src_lens, max_src_len, mels=None, mel_lens=None, max_mel_len=None,
+                p_targets=None, e_targets=None, p_control=1.0, e_control=1.0):
+        """model/fastspeech2_align.py:30-100, inference branch.  ``speakers`` is accepted and ignored
+        (no speaker embedding exists in the reference; multi_speaker is False).
+
+        Extension for multi-GPU global-pad mode: ``max_mel_len`` may be an int >= max(mel_lens)
+        or a callable ``f(local_max_tensor) -> int`` (e.g. ``sharding.global_max``); the mel axis is then padded
+        (and masked) to that length.  The reference itself cannot run with max_mel_len set at inference
+        (its mask is built from max(mel_len), model/modules.py:136-137)."""
+        if mel_lens is not None:
+            raise NotImplementedError(
+                "teacher-forced / training branch is out of scope; in the reference it calls an undefined "
+                "self._calculate_duration (model/fastspeech2_align.py:57)")
+        if not texts.is_cuda:
+            raise RuntimeError("inputs must live on the MI355X (cuda) device; there is no CPU path")
+        if self._device != texts.device:
+            self.to(texts.device)
+        lib, dev = self._lib, self._device
+        B, L = int(texts.shape[0]), int(texts.shape[1])
+        if int(max_src_len) != L:
+            raise ValueError(f"max_src_len ({int(max_src_len)}) must equal texts.shape[1] ({L})")
+        texts_c = texts.long().contiguous()
+        lens_c = src_lens.to(device=dev, dtype=torch.long).contiguous()
+        with torch.cuda.device(dev):
+            st = _lib.stream_ptr(dev)
+            f32 = dict(dtype=torch.float32, device=dev)
+            log_d = torch.empty(B, L, **f32)
+            d_rounded = torch.empty(B, L, **f32)
+            src_masks = torch.empty(B, L, dtype=torch.bool, device=dev)
+            out_mel_lens = torch.empty(B, dtype=torch.long, device=dev)
+            ws_enc_bytes = lib.ns_encoder_ws_bytes(self._h, B, L)
+            ws_enc = self._workspace("enc", ws_enc_bytes)
+            _lib.check(lib.ns_forward_durations(self._h, _lib.ptr(texts_c), _lib.ptr(lens_c), B, L, 1.0,
+                                                _lib.ptr(ws_enc), ws_enc.numel(), _lib.ptr(log_d), _lib.ptr(d_rounded),
+                                                _lib.ptr(src_masks), _lib.ptr(out_mel_lens), st), "ns_forward_durations")
+            # the one device->host read: output shapes depend on max(mel_len)
+            # (the reference syncs here too: utils/tools.py:92, plus B*L .item() calls at model/modules.py:222)
+            if callable(max_mel_len):
+                T = int(max_mel_len(out_mel_lens.max()))
+            else:
+                T = int(out_mel_lens.max().item())
+                if max_mel_len is not None:
+                    if int(max_mel_len) < T:
+                        raise ValueError(f"max_mel_len ({int(max_mel_len)}) is smaller than the longest utterance ({T})")
+                    T = int(max_mel_len)
+            n_mel = self._cfg.n_mel
+            mel = torch.empty(B, T, n_mel, **f32)
+            post = torch.empty(B, T, n_mel, **f32)
+            p_pred = torch.empty(B, T, **f32)
+            e_pred = torch.empty(B, T, **f32)
+            mel_masks = torch.empty(B, T, dtype=torch.bool, device=dev)
+            tg = []
+            for name, t in (("p_targets", p_targets), ("e_targets", e_targets)):
+                # forward() hands p_targets / e_targets to the variance adaptor in the inference branch too
+                # (model/fastspeech2_align.py:70-78): the embedding then comes from bucketize(target)
+                if t is not None:
+                    if tuple(t.shape) != (B, T):
+                        raise ValueError(f"{name} must have shape {(B, T)}, got {tuple(t.shape)}")
+                    t = t.to(device=dev, dtype=torch.float32).contiguous()
+                tg.append(t)
+            if T > 0:
+                ws_dec_bytes = lib.ns_decoder_ws_bytes(self._h, B, L, T)
+                ws_dec = self._workspace("dec", ws_dec_bytes)
+                _lib.check(lib.ns_forward_mel(self._h, B, L, T, _lib.ptr(out_mel_lens), float(p_control), float(e_control),
+                                              _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(ws_enc), _lib.ptr(ws_dec), ws_dec.numel(), _lib.ptr(mel),
+                                              _lib.ptr(post), _lib.ptr(p_pred), _lib.ptr(e_pred), _lib.ptr(mel_masks), st),
+                           "ns_forward_mel")
+        return (mel, post, p_pred, e_pred, log_d, d_rounded, src_masks, mel_masks, src_lens, out_mel_lens, None, None)

@@ -88,6 +88,23 @@ def test_per_module_intermediates(name):
         chk(torch.from_numpy(cap["pitch_pred.in0"]) + p_emb, cap["energy_pred.in0"], "pitch embedding add")
 
 
+def test_targets_branch():
+    """p_targets / e_targets handed to forward() in the inference branch (model/modules.py:82-84,93-95)."""
+    meta, z = load_golden("e2e_tiny_targets")
+    cfg, sd = weights_for(meta)
+    with torch.no_grad():
+        out = orc.forward(orc.to_torch_weights(sd), cfg, torch.from_numpy(z["speakers"]), torch.from_numpy(z["texts"]),
+                          torch.from_numpy(z["in_src_lens"]), int(meta["L"]),
+                          p_targets=torch.from_numpy(z["p_targets"]), e_targets=torch.from_numpy(z["e_targets"]))
+    for i, n in enumerate(NAMES):
+        got, ref = out[i].numpy(), z[n]
+        assert got.shape == ref.shape
+        if got.dtype == np.float32:
+            assert np.abs(got - ref).max() <= TOL, n
+        else:
+            assert np.array_equal(got, ref), n
+
+
 def test_neighbours_bit_identical():
     """F3 case (c): same utterance, two different longer neighbours → identical results."""
     meta, z = load_golden("e2e_tiny_neighbours")
