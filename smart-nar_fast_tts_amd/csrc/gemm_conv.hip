@@ -11,32 +11,48 @@
 // window.  K runs tap-major (k = j*Cin + c), BK divides Cin, so one K-chunk touches one tap.
 //
 // Tiling (wave64, 4 waves = 2x2 per workgroup): block tile BMxBN, wave tile (BM/2)x(BN/2) as a grid of
-// 32x32 MFMA tiles, K-chunk BK staged through LDS (double buffered, register-staged prefetch so the HBM/L2
-// latency of chunk t+1 hides under the MFMAs of chunk t).  One K-chunk of a 128x128x32 tile is 64 MFMAs
-// x 64 cycles per wave, far longer than a global load, so one barrier per chunk is enough.
+// 32x32 MFMA tiles, K-chunk BK double-buffered in LDS.
+//
+// Staging is LDS-DMA (`buffer_load_dwordx4 ... lds`): operands go HBM/L2 -> LDS without touching VGPRs, the
+// zero padding of the convolution and the M/N tile tails come for free from the buffer descriptor's
+// out-of-range rule (a lane whose voffset is the OOR marker writes zeros to LDS), and the per-chunk cost on the
+// issuing wave is 8 DMA instructions with a scalar offset bump — no address VALU, no ds_write pass, nothing
+// between a chunk's MFMAs but 16 ds_read_b128.  (Measured on the dominant shape: register-staged version
+// 106 TFLOP/s, its compute-only ablation 137; see tools/lab.)
+//
+// The DMA destination is lane-linear (wave-uniform base + lane*16 B), so rows cannot be padded; bank conflicts
+// of the fragment reads are removed by an XOR swizzle applied on the SOURCE side: 16-byte slot s of tile row r
+// holds column chunk c = s ^ f(r), f(r) = (r>>1)&7 for 128-B rows (BK=32), (r>>2)&3 for 64-B rows (BK=16);
+// the reads apply the same XOR.  With it every ds_read_b128 lane group touches 16 distinct 16-B bank slots.
 //
 // Operand reads use the freedom to permute k identically on both operands: lane-half h of MFMA step e in
 // group g consumes k = 8g + 4h + e, so each lane reads its 4 steps' operands with ONE ds_read_b128.
-// Row stride BK+4 floats makes those b128 reads bank-conflict free (MI355X_MICROARCH.md §LDS).
 #include "kernels.h"
 
 namespace ns {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int OOR = (int)0x80000000;  // voffset marker: beyond num_records -> the DMA writes zeros
 
 template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemm p, int ntn) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type does not exist in the host pass; it only needs the stub
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int LS = BK + 4;
-  constexpr int TPR = BK / 4;        // float4 lanes per tile row
-  constexpr int RPP = 256 / TPR;     // tile rows per pass
-  constexpr int PA = BM / RPP, PB = BN / RPP;
-  static_assert(PA >= 1 && PB >= 1, "tile too small for 256 threads");
+  constexpr int CPR = BK / 4;         // 16-B chunks per tile row
+  constexpr int RPI = 64 / CPR;       // tile rows one wave-wide DMA instruction fills
+  constexpr int IA = BM / (4 * RPI);  // DMA instructions per wave per chunk, A and B
+  constexpr int IB = BN / (4 * RPI);
+  constexpr int FSH = (BK == 64) ? 0 : (BK == 32) ? 1 : 2;
+  constexpr int FMSK = CPR - 1;
+  static_assert(BK == 64 || BK == 32 || BK == 16, "BK");
+  static_assert(IA >= 1 && IB >= 1, "tile too small for 4 waves");
 
-  __shared__ __attribute__((aligned(16))) float As[2][BM * LS];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LS];
+  __shared__ __attribute__((aligned(16))) float As[2][BM * BK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * BK];
 
   // XCD-aware bijective remap: consecutive tile ids (same M-tile, all N-tiles) land on one XCD / one L2
   const int nblk = gridDim.x, bid = blockIdx.x;
@@ -44,59 +60,55 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemm p, int ntn) {
   const int id2 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int m0 = (id2 / ntn) * BM, n0 = (id2 % ntn) * BN;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wid >> 1) * WM, wn0 = (wid & 1) * WN;
-  const int lrow = tid / TPR, lcol = (tid % TPR) * 4;
 
   const int Kt = p.KW * p.Cin;
-  const int cpj = p.Cin / BK;        // chunks per tap
+  const int cpj = p.Cin / BK;  // chunks per tap
   const int nch = p.KW * cpj;
 
-  // per-thread A rows: global row and position inside the utterance (fixed across chunks)
-  int a_t[PA];
-  bool a_ok[PA];
-  const float* a_ptr[PA];
+  // block-relative descriptors: A rows are addressed from row (m0 - pad), B rows from row n0
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.X + ((ptrdiff_t)m0 - p.pad) * p.ldx), (short)0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)n0 * Kt), (short)0, 0x7FFFFFFF, 0x00020000);
+
+  // per-lane DMA geometry: instruction i of this wave fills tile rows (wid*I + i)*RPI + lane/CPR, slot lane%CPR
+  const int lr = lane / CPR, ls = lane % CPR;
+  int a_row[IA], a_t[IA], a_col[IA];
+  bool a_ok[IA];
 #pragma unroll
-  for (int i = 0; i < PA; ++i) {
-    const int m = m0 + lrow + i * RPP;
+  for (int i = 0; i < IA; ++i) {
+    const int r = (wid * IA + i) * RPI + lr;
+    const int m = m0 + r;
+    a_row[i] = r;
     a_ok[i] = m < p.M;
     a_t[i] = a_ok[i] ? (m % p.S) : 0;
-    a_ptr[i] = p.X + (size_t)(a_ok[i] ? m : 0) * p.ldx + lcol;
+    a_col[i] = (ls ^ ((r >> FSH) & FMSK)) * 4;
   }
-  const float* b_ptr[PB];
-  bool b_ok[PB];
+  int vb[IB];
 #pragma unroll
-  for (int i = 0; i < PB; ++i) {
-    const int n = n0 + lrow + i * RPP;
-    b_ok[i] = n < p.N;
-    b_ptr[i] = p.W + (size_t)(b_ok[i] ? n : 0) * Kt + lcol;
+  for (int i = 0; i < IB; ++i) {
+    const int r = (wid * IB + i) * RPI + lr;
+    vb[i] = (n0 + r < p.N) ? (r * Kt + (ls ^ ((r >> FSH) & FMSK)) * 4) * 4 : OOR;
   }
-
-  f32x4 ra[PA], rb[PB];
-  auto load_chunk = [&](int ch) {
-    const int j = ch / cpj, c0 = (ch - j * cpj) * BK;
-    const int sh = j - p.pad;
+  int va[IA];
+  auto set_tap = [&](int j) {
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int ts = a_t[i] + sh;
-      if (a_ok[i] && ts >= 0 && ts < p.S)
-        ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + (ptrdiff_t)sh * p.ldx + c0);
-      else
-        ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      if (b_ok[i])
-        rb[i] = *reinterpret_cast<const f32x4*>(b_ptr[i] + (size_t)ch * BK);
-      else
-        rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < IA; ++i) {
+      const int ts = a_t[i] + j - p.pad;
+      va[i] = (a_ok[i] && ts >= 0 && ts < p.S) ? ((a_row[i] + j) * p.ldx + a_col[i]) * 4 : OOR;
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto dma_chunk = [&](int buf, int cc, int ch) {
+    const int soA = cc * BK * 4, soB = ch * BK * 4;
 #pragma unroll
-    for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(&As[buf][(lrow + i * RPP) * LS + lcol]) = ra[i];
+    for (int i = 0; i < IA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)&As[buf][(wid * IA + i) * RPI * BK], 16, va[i], soA, 0, 0);
 #pragma unroll
-    for (int i = 0; i < PB; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + i * RPP) * LS + lcol]) = rb[i];
+    for (int i = 0; i < IB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)&Bs[buf][(wid * IB + i) * RPI * BK], 16, vb[i], soB, 0, 0);
   };
 
   f32x16 acc[TM][TN];
@@ -107,23 +119,36 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemm p, int ntn) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  load_chunk(0);
-  store_chunk(0);
+  // fragment read offsets (floats): row (lane&31), slot ((2g + h) ^ f(row)); f is the same for every 32-row tile
+  const int frow = lane & 31, fh = lane >> 5;
+  int foff[BK / 8];
+#pragma unroll
+  for (int g = 0; g < BK / 8; ++g) foff[g] = frow * BK + (((2 * g + fh) ^ ((frow >> FSH) & FMSK)) * 4);
+
+  int j = 0, cc = 0;
+  set_tap(0);
+  dma_chunk(0, 0, 0);
   __syncthreads();
 
-  const int frag_off = (lane & 31) * LS + (lane >> 5) * 4;
   for (int ch = 0; ch < nch; ++ch) {
     const int buf = ch & 1;
-    if (ch + 1 < nch) load_chunk(ch + 1);
-    const float* as = &As[buf][wm0 * LS + frag_off];
-    const float* bs = &Bs[buf][wn0 * LS + frag_off];
+    if (ch + 1 < nch) {
+      if (++cc == cpj) {
+        cc = 0;
+        ++j;
+        set_tap(j);
+      }
+      dma_chunk(buf ^ 1, cc, ch + 1);
+    }
+    const float* as = &As[buf][wm0 * BK];
+    const float* bs = &Bs[buf][wn0 * BK];
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
       f32x4 a[TM], b[TN];
 #pragma unroll
-      for (int mi = 0; mi < TM; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * LS + g * 8);
+      for (int mi = 0; mi < TM; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * BK + foff[g]);
 #pragma unroll
-      for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * LS + g * 8);
+      for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * BK + foff[g]);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -132,8 +157,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemm p, int ntn) {
           for (int ni = 0; ni < TN; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], acc[mi][ni], 0, 0, 0);
     }
-    if (ch + 1 < nch) store_chunk(buf ^ 1);
-    __syncthreads();
+    __syncthreads();  // drains this iteration's DMA (vmcnt) and fences the buffer swap
   }
 
   // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -157,6 +181,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemm p, int ntn) {
       }
     }
   }
+#endif
 }
 
 template <int BM, int BN, int BK>
@@ -169,11 +194,15 @@ static hipError_t launch_t(const ConvGemm& p, hipStream_t st) {
 hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if (p.Cin % 16 != 0 || (p.ldx & 3) != 0) return hipErrorInvalidValue;
+  // descriptor offsets are 31-bit: a tile's rows (BM + KW) * ldx and BN * K floats must stay below 2^29 floats
+  if ((long long)(128 + p.KW) * p.ldx >= (1ll << 29) || (long long)128 * p.KW * p.Cin >= (1ll << 29)) return hipErrorInvalidValue;
   const bool bk32 = (p.Cin % 32) == 0;
-  // 128x128 tiles when they still give every CU (256) about two workgroups; 64x64 otherwise
-  const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  const bool big = tiles128 >= 384 && p.N >= 96;
-  if (big) return bk32 ? launch_t<128, 128, 32>(p, st) : launch_t<128, 128, 16>(p, st);
+  // Tile choice (tools/lab/gemm_lab.hip sweep on the path's shapes, MI355X): the kernel is fastest with MANY small
+  // independent workgroups per CU (their barrier/DMA phases interleave and keep the matrix pipe fed), so the
+  // 64-row tile wins over 128x128 everywhere; 64x128 halves the B-operand traffic when N and the grid allow it.
+  const long tiles_wide = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
+  const bool wide = p.N >= 128 && tiles_wide >= 1024;
+  if (wide) return bk32 ? launch_t<64, 128, 32>(p, st) : launch_t<64, 128, 16>(p, st);
   return bk32 ? launch_t<64, 64, 32>(p, st) : launch_t<64, 64, 16>(p, st);
 }
 
