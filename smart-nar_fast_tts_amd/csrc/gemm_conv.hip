@@ -54,11 +54,27 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemm p, int ntn) {
   __shared__ __attribute__((aligned(16))) float As[2][BM * BK];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * BK];
 
-  // XCD-aware bijective remap: consecutive tile ids (same M-tile, all N-tiles) land on one XCD / one L2
+  // XCD-aware bijective remap.  Workgroup b runs on XCD b%8 (observed, used for speed only).  Tiles are ordered
+  // "super-row by super-row": the M-tiles are split into 8 contiguous groups, and inside a group the order is
+  // N-tile major / M-tile minor.  XCD x takes the x-th contiguous slice of that order, i.e. (up to a few tiles)
+  // one group: its activation rows (a few MB) stay resident in that XCD's 4 MiB L2 while one weight slice
+  // (BN x K floats) at a time streams through, instead of every workgroup re-fetching the whole weight matrix.
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-  const int id2 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int m0 = (id2 / ntn) * BM, n0 = (id2 % ntn) * BN;
+  int pos = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int ntm = nblk / ntn, mq = ntm >> 3, mr = ntm & 7;
+  int tile_m = 0, tile_n = 0, mstart = 0;
+  for (int x = 0; x < 8; ++x) {
+    const int gm = mq + (x < mr ? 1 : 0), gsz = gm * ntn;
+    if (pos < gsz) {
+      tile_n = pos / gm;
+      tile_m = mstart + pos % gm;
+      break;
+    }
+    pos -= gsz;
+    mstart += gm;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
