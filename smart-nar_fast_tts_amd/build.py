@@ -12,6 +12,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libnarfs2.so")
 SOURCES = ["gemm_conv.hip", "attention.hip", "rowops.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+# attention keeps its O^T / S^T accumulators in architectural VGPRs (gfx950 has one unified 512-entry file): the
+# online softmax touches them with VALU ops, and in AGPR form hipcc shuttles all 64+16 registers through
+# v_accvgpr_read/write every key tile.
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -37,7 +41,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -698,6 +698,10 @@ extern "C" int ns_op_postnet(ns_model* m, const float* mel, int B, int T, float*
   NS_OP_PROLOGUE(B, T);
   return postnet(m, mel, B, T, nullptr, out, sc, st);
 }
+extern "C" int ns_op_attention_core(const float* qkv, const int64_t* lens, int B, int S, int H, int dk, float* out, void* stream) {
+  NS_HIP(launch_attention(qkv, (const long long*)lens, B, S, H, dk, out, (hipStream_t)stream));
+  return 0;
+}
 extern "C" int ns_op_ffn_conv1(ns_model* m, const char* prefix, const float* x, int B, int S, float* hidden, void* stream) {
   NS_TRY(check_ready(m));
   const LayerW* L; int d, H;

@@ -51,8 +51,14 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemm p, int ntn) {
   static_assert(BK == 64 || BK == 32 || BK == 16, "BK");
   static_assert(IA >= 1 && IB >= 1, "tile too small for 4 waves");
 
-  __shared__ __attribute__((aligned(16))) float As[2][BM * BK];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * BK];
+  // Four DISTINCT LDS objects (not [2][...] arrays) and a 2x unrolled K loop with a static buffer index: hipcc tracks
+  // in-flight LDS-DMA per LDS object, so a ds_read from As0 does not wait for a DMA that is filling As1.  With one
+  // object per operand it inserted `s_waitcnt vmcnt(..)` in front of the first fragment read of every chunk, exposing
+  // the whole L2/HBM latency of the prefetch it had just issued.
+  __shared__ __attribute__((aligned(16))) float As0[BM * BK];
+  __shared__ __attribute__((aligned(16))) float As1[BM * BK];
+  __shared__ __attribute__((aligned(16))) float Bs0[BN * BK];
+  __shared__ __attribute__((aligned(16))) float Bs1[BN * BK];
 
   // XCD-aware bijective remap.  Workgroup b runs on XCD b%8 (observed, used for speed only).  Tiles are ordered
   // "super-row by super-row": the M-tiles are split into 8 contiguous groups, and inside a group the order is
@@ -117,14 +123,14 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemm p, int ntn) {
       va[i] = (a_ok[i] && ts >= 0 && ts < p.S) ? ((a_row[i] + j) * p.ldx + a_col[i]) * 4 : OOR;
     }
   };
-  auto dma_chunk = [&](int buf, int cc, int ch) {
+  auto dma_chunk = [&](float* As, float* Bs, int cc, int ch) {
     const int soA = cc * BK * 4, soB = ch * BK * 4;
 #pragma unroll
     for (int i = 0; i < IA; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)&As[buf][(wid * IA + i) * RPI * BK], 16, va[i], soA, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)&As[(wid * IA + i) * RPI * BK], 16, va[i], soA, 0, 0);
 #pragma unroll
     for (int i = 0; i < IB; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)&Bs[buf][(wid * IB + i) * RPI * BK], 16, vb[i], soB, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)&Bs[(wid * IB + i) * RPI * BK], 16, vb[i], soB, 0, 0);
   };
 
   f32x16 acc[TM][TN];
@@ -143,21 +149,21 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemm p, int ntn) {
 
   int j = 0, cc = 0;
   set_tap(0);
-  dma_chunk(0, 0, 0);
+  dma_chunk(As0, Bs0, 0, 0);
   __syncthreads();
 
-  for (int ch = 0; ch < nch; ++ch) {
-    const int buf = ch & 1;
+  // one K-chunk: prefetch chunk ch+1 into the OTHER buffer pair, then 4*TM*TN*(BK/8) MFMAs on this one
+  auto step = [&](int ch, const float* Ac, const float* Bc, float* An, float* Bn) {
     if (ch + 1 < nch) {
       if (++cc == cpj) {
         cc = 0;
         ++j;
         set_tap(j);
       }
-      dma_chunk(buf ^ 1, cc, ch + 1);
+      dma_chunk(An, Bn, cc, ch + 1);
     }
-    const float* as = &As[buf][wm0 * BK];
-    const float* bs = &Bs[buf][wn0 * BK];
+    const float* as = Ac + wm0 * BK;
+    const float* bs = Bc + wn0 * BK;
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
       f32x4 a[TM], b[TN];
@@ -173,7 +179,11 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemm p, int ntn) {
           for (int ni = 0; ni < TN; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], acc[mi][ni], 0, 0, 0);
     }
-    __syncthreads();  // drains this iteration's DMA (vmcnt) and fences the buffer swap
+    __syncthreads();  // drains this chunk's DMA (vmcnt) and fences the buffer swap
+  };
+  for (int ch = 0; ch < nch; ch += 2) {
+    step(ch, As0, Bs0, As1, Bs1);
+    if (ch + 1 < nch) step(ch + 1, As1, Bs1, As0, Bs0);
   }
 
   // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

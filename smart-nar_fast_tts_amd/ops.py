@@ -192,3 +192,16 @@ def ffn_conv1(model, prefix, x, out=None):
         out = torch.empty(B, S, model._cfg.d_inner, dtype=torch.float32, device=x.device)
     _lib.check(model._lib.ns_op_ffn_conv1(model._h, prefix.encode(), _lib.ptr(x), B, S, _lib.ptr(out), _st(x)), "ffn_conv1")
     return out
+
+
+def attention_core(qkv, lens, n_head: int):
+    """ScaledDotProductAttention on already-projected, head-packed q/k/v (transformer/Modules.py:14-25):
+    qkv [B,S,3*d] (Q | K | V, head h at h*dk inside each) -> merged heads [B,S,d]."""
+    lib = _lib.load()
+    B, S, d3 = qkv.shape
+    d = d3 // 3
+    qkv = qkv.contiguous()
+    out = torch.empty(B, S, d, dtype=torch.float32, device=qkv.device)
+    lens_p = _lib.ptr(lens.long().contiguous()) if lens is not None else _lib.ptr(None)
+    _lib.check(lib.ns_op_attention_core(_lib.ptr(qkv), lens_p, B, S, n_head, d // n_head, _lib.ptr(out), _st(qkv)), "attention_core")
+    return out

@@ -32,7 +32,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int DK>
+template <int DK, int ABL = 0>
 __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, const long long* __restrict__ lens,
                                                     int S, int d, float c_scale, float* __restrict__ out) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -47,12 +47,8 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   static_assert(DK == 32 || DK == 64 || DK == 128, "d_k");
   static_assert(NI >= 1 && RPI * CPR == 64, "tile/DMA geometry");
 
-  // four DISTINCT LDS objects + a 2x unrolled tile loop with static buffer roles: hipcc tracks in-flight LDS-DMA per
-  // LDS object, so reading K1/V0 does not wait for the DMA that is filling K0/V1 (see gemm_conv.hip)
-  __shared__ __attribute__((aligned(16))) float Ks0[BC * DK];
-  __shared__ __attribute__((aligned(16))) float Ks1[BC * DK];
-  __shared__ __attribute__((aligned(16))) float Vs0[BC * DK];
-  __shared__ __attribute__((aligned(16))) float Vs1[BC * DK];
+  __shared__ __attribute__((aligned(16))) float Ks[2][BC * DK];
+  __shared__ __attribute__((aligned(16))) float Vs[2][BC * DK];
 
   const int b = blockIdx.z, hd = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -81,15 +77,15 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     vv[i] = (r * ld + ls * 4) * 4;
   }
   const int tile_step = BC * ld * 4;  // bytes per key tile
-  auto dma_k = [&](float* Kd, int kt) {
+  auto dma_k = [&](int buf, int kt) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)&Kd[(wid * NI + i) * RPI * DK], 16, vk[i] + kt * tile_step, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)&Ks[buf][(wid * NI + i) * RPI * DK], 16, vk[i] + kt * tile_step, 0, 0, 0);
   };
-  auto dma_v = [&](float* Vd, int kt) {
+  auto dma_v = [&](int buf, int kt) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)&Vd[(wid * NI + i) * RPI * DK], 16, vv[i] + kt * tile_step, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)&Vs[buf][(wid * NI + i) * RPI * DK], 16, vv[i] + kt * tile_step, 0, 0, 0);
   };
 
   // Q^T operand: lane (q, h) keeps Q[q][8g + 4h + e]
@@ -115,10 +111,11 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     for (int g = 0; g < NG; ++g) koff[g] = qi * DK + (((2 * g + h) ^ f) * 4);
   }
 
-  // S^T[key][q] = sum_d K[key][d] Q[q][d] for the K tile at kp
-  auto qk = [&](const float* kp, f32x16& s) {
+  // S^T[key][q] = sum_d K[key][d] Q[q][d] for the tile in Ks[buf]
+  auto qk = [&](int buf, f32x16& s) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const float* kp = &Ks[buf][0];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const f32x4 kf = *reinterpret_cast<const f32x4*>(kp + koff[g]);
@@ -157,8 +154,8 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     return alpha;
   };
   // O^T[d][q] = alpha * O^T[d][q] + sum_key V[key][d] P[q][key]   (MFMA step r <-> key(r,h), B operand = p[r])
-  auto pv = [&](const float* vtile, const f32x16& pr, float alpha) {
-    const float* vp = vtile + (4 * h) * DK + qi;
+  auto pv = [&](int buf, const f32x16& pr, float alpha) {
+    const float* vp = &Vs[buf][(4 * h) * DK + qi];
     if (__any(alpha != 1.0f)) {  // wave-uniform; rare after the first tile (lazy reference point)
 #pragma unroll
       for (int db = 0; db < NDB; ++db)
@@ -176,34 +173,28 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   };
 
   if (nkt > 0) {
-    dma_k(Ks0, 0);
-    dma_v(Vs0, 0);
-    if (nkt > 1) dma_k(Ks1, 1);
+    dma_k(0, 0);
+    dma_v(0, 0);
+    if (nkt > 1) dma_k(1, 1);
   }
   __syncthreads();
 
   f32x16 s_cur, s_next;
-  if (nkt > 0) qk(Ks0, s_cur);
+  if (nkt > 0) qk(0, s_cur);
   __syncthreads();  // every wave has read K(0) before the loop's first DMA reuses its buffer
-
-  // one key tile kt (not the last): K(kt) and V(kt-1) are dead -> refill their buffers with K(kt+2) / V(kt+1);
-  // matrix pipe: next tile's scores, VALU: this tile's softmax, then P(kt) V(kt)
-  auto tile = [&](int kt, float* Kdead, const float* Knext, const float* Vcur, float* Vdead) {
-    if (kt + 2 < nkt) dma_k(Kdead, kt + 2);
-    dma_v(Vdead, kt + 1);
-    qk(Knext, s_next);
-    const float alpha = softmax_tile(kt, s_cur);
-    pv(Vcur, s_cur, alpha);
+  for (int kt = 0; kt + 1 < nkt; ++kt) {
+    // K(kt) and V(kt-1) are dead: refill their buffers with K(kt+2) and V(kt+1)
+    if (!(ABL & 1)) { if (kt + 2 < nkt) dma_k(kt & 1, kt + 2);
+    dma_v((kt + 1) & 1, kt + 1); }
+    qk((kt + 1) & 1, s_next);                  // matrix pipe: next tile's scores ...
+    const float alpha = (ABL & 4) ? 1.0f : softmax_tile(kt, s_cur);
+    pv(kt & 1, s_cur, alpha);
     s_cur = s_next;
-    __syncthreads();  // drains the DMA issued above and fences the buffer reuse
-  };
-  for (int kt = 0; kt + 1 < nkt; kt += 2) {
-    tile(kt, Ks0, Ks1, Vs0, Vs1);
-    if (kt + 2 < nkt) tile(kt + 1, Ks1, Ks0, Vs1, Vs0);
+    if (!(ABL & 2)) __syncthreads();
   }
   if (nkt > 0) {
     const float alpha = softmax_tile(nkt - 1, s_cur);
-    pv(((nkt - 1) & 1) ? Vs1 : Vs0, s_cur, alpha);
+    pv((nkt - 1) & 1, s_cur, alpha);
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -221,15 +212,16 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
 #endif
 }
 
-hipError_t launch_attention(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, hipStream_t st) {
+template <int ABL>
+hipError_t launch_attention_abl(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, hipStream_t st) {
   if (B <= 0 || S <= 0) return hipSuccess;
   const int d = H * dk;
   if ((long long)S * 3 * d * 4 >= (1ll << 31)) return hipErrorInvalidValue;  // 31-bit descriptor offsets per utterance
   const float c = 1.4426950408889634f / sqrtf((float)dk);
   dim3 grid((S + 127) / 128, H, B), block(256);
-  if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out);
-  else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out);
-  else if (dk == 32) hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out);
+  if (dk == 128) hipLaunchKernelGGL((k_attention<128, ABL>), grid, block, 0, st, qkv, lens, S, d, c, out);
+  else if (dk == 64) hipLaunchKernelGGL((k_attention<64, ABL>), grid, block, 0, st, qkv, lens, S, d, c, out);
+  else if (dk == 32) hipLaunchKernelGGL((k_attention<32, ABL>), grid, block, 0, st, qkv, lens, S, d, c, out);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
