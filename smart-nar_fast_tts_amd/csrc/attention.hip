@@ -152,6 +152,10 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
       s[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
       psum += s[r];
     }
+    // keep the exponentials in THIS scheduling region (the one that holds the QK^T MFMAs): without the pin the
+    // optimiser sinks them below pv()'s branch, next to their only consumers
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(s[r]));
     l_run = l_run * alpha + psum;
     m_run = m_new;
     return alpha;
