@@ -41,6 +41,8 @@ typedef struct ns_config {
   int32_t n_mel;            /* 80 */
   int32_t postnet_dim, postnet_k, postnet_n; /* 512, 5, 5 */
   int32_t pitch_frame_level, energy_frame_level; /* 1 = frame_level (shipped config), 0 = phoneme_level */
+  int32_t length_regulator; /* 0 = LengthRegulator (what the reference wires, model/modules.py:22); 1 = EXTENSION: the
+                               reference's unused GaussianUpsampling (model/modules.py:162-192) in its place */
 } ns_config;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -73,9 +75,14 @@ size_t ns_decoder_ws_bytes(const ns_model* m, int B, int L, int T);
  * The encoder output and the duration prefix sums stay in ws_enc for phase 2.
  * The caller reads mel_lens back (the one unavoidable device->host read: the output tensors are
  * shaped by max(mel_lens), model/modules.py:136-137) and allocates the phase-2 outputs. */
+/* phoneme_level pitch / energy (preprocess.yaml `feature`, model/modules.py:117-126) are predicted here, on the
+ * encoder output: p_control / e_control / p_targets / e_targets / p_pred / e_pred ([B,L]) are used by THIS call for a
+ * phoneme_level feature and by ns_forward_mel ([B,T]) for a frame_level one; pass NULL where not applicable. */
 int ns_forward_durations(ns_model* m, const int64_t* texts, const int64_t* src_lens, int B, int L,
-                         float d_control, void* ws_enc, size_t ws_enc_bytes,
-                         float* log_d, float* d_rounded, uint8_t* src_mask, int64_t* mel_lens, void* stream);
+                         float d_control, float p_control, float e_control, const float* p_targets, const float* e_targets,
+                         void* ws_enc, size_t ws_enc_bytes,
+                         float* log_d, float* d_rounded, uint8_t* src_mask, int64_t* mel_lens, float* p_pred, float* e_pred,
+                         void* stream);
 
 /* Phase 2: LengthRegulator + frame-level pitch/energy + MelDecoder + mel_linear + PostNet (+ residual).
  * T must be max(mel_lens) (or a caller-chosen max_mel_len >= it, model/modules.py:128-129 semantics).

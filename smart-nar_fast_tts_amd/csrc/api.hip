@@ -108,9 +108,8 @@ extern "C" int ns_create(const ns_config* cfg, ns_model** out) {
   }
   if (!(c.ffn_k1 & 1) || !(c.ffn_k2 & 1) || !(c.vp_kernel & 1) || !(c.postnet_k & 1))
     return fail("ns_create: kernel sizes must be odd");
+  if (c.length_regulator != 0 && c.length_regulator != 1) return fail("ns_create: length_regulator must be 0 (hard) or 1 (gaussian)");
   if (c.vp_kernel != 3) return fail("ns_create: variance predictor conv1d_2 hard-codes padding=1 (model/modules.py:267); kernel_size must be 3");
-  if (!c.pitch_frame_level || !c.energy_frame_level)
-    return fail("ns_create: phoneme_level pitch/energy is not built yet (SURVEY.md §8 f4); the shipped config is frame_level");
   ns_model* m = new ns_model();
   m->cfg = c;
   const int d = c.d_enc, npos = c.max_seq_len + 1;
@@ -348,6 +347,7 @@ extern "C" size_t ns_encoder_ws_bytes(const ns_model* m, int B, int L) {
   Bump bp(nullptr, 0);
   bp.f((size_t)B * L * m->cfg.d_enc);  // encoder output (kept for phase 2)
   bp.raw((size_t)B * L * sizeof(int32_t));  // duration prefix sums (kept for phase 2)
+  bp.f((size_t)B * L);                       // rounded durations (kept for phase 2: Gaussian length regulator)
   carve(m->cfg, bp, (size_t)B * L, L);
   return bp.off + 256;
 }
@@ -496,8 +496,9 @@ static int decoder_stack(const ns_model* m, float* x, const long long* lens, int
 
 // ------------------------------------------------------------------------------------------- the forward
 extern "C" int ns_forward_durations(ns_model* m, const int64_t* texts, const int64_t* src_lens, int B, int L, float d_control,
+                                    float p_control, float e_control, const float* p_targets, const float* e_targets,
                                     void* ws_enc, size_t ws_bytes, float* log_d, float* d_rounded, uint8_t* src_mask,
-                                    int64_t* mel_lens, void* stream) {
+                                    int64_t* mel_lens, float* p_pred, float* e_pred, void* stream) {
   NS_TRY(check_ready(m));
   if (B <= 0 || L <= 0) return fail("ns_forward_durations: empty batch");
   if (ws_bytes < ns_encoder_ws_bytes(m, B, L)) return fail("ns_forward_durations: workspace too small");
@@ -506,13 +507,27 @@ extern "C" int ns_forward_durations(ns_model* m, const int64_t* texts, const int
   Bump bp(ws_enc, ws_bytes);
   float* enc_out = bp.f((size_t)B * L * c.d_enc);
   int32_t* cum = (int32_t*)bp.raw((size_t)B * L * sizeof(int32_t));
+  float* dur_keep = bp.f((size_t)B * L);
   Scratch sc = carve(c, bp, (size_t)B * L, L);
   const long long* lens = (const long long*)src_lens;
   NS_HIP(launch_mask_from_lengths(lens, B, L, src_mask, st));
   NS_TRY(encoder(m, (const long long*)texts, lens, B, L, enc_out, sc, st));
   NS_TRY(predictor(m, m->pred[0], enc_out, lens, B, L, 1.0f, nullptr, log_d, nullptr, nullptr, nullptr, nullptr, sc, st));
+  // phoneme_level features are predicted on the encoder output, before the length regulator, pitch first, and
+  // added in place (model/modules.py:117-126); the duration predictor above saw x before these adds (:116)
+  if (!c.pitch_frame_level) {
+    if (!p_pred) return fail("ns_forward_durations: phoneme_level pitch needs a p_pred [B,L] output");
+    NS_TRY(predictor(m, m->pred[1], enc_out, lens, B, L, p_control, p_targets, p_pred, m->P(m->pitch_bins), m->P(m->pitch_emb),
+                     nullptr, enc_out, sc, st));
+  }
+  if (!c.energy_frame_level) {
+    if (!e_pred) return fail("ns_forward_durations: phoneme_level energy needs an e_pred [B,L] output");
+    NS_TRY(predictor(m, m->pred[2], enc_out, lens, B, L, e_control, e_targets, e_pred, m->P(m->energy_bins), m->P(m->energy_emb),
+                     nullptr, enc_out, sc, st));
+  }
   NS_HIP(launch_duration_round(log_d, B * L, d_control, d_rounded, st));
   NS_HIP(launch_duration_scan(d_rounded, B, L, cum, (long long*)mel_lens, st));
+  NS_HIP(hipMemcpyAsync(dur_keep, d_rounded, (size_t)B * L * sizeof(float), hipMemcpyDeviceToDevice, st));
   return 0;
 }
 
@@ -529,22 +544,45 @@ extern "C" int ns_forward_mel(ns_model* m, int B, int L, int T, const int64_t* m
   Bump be(const_cast<void*>(ws_enc), (size_t)-1);
   const float* enc_out = be.f((size_t)B * L * c.d_enc);
   const int32_t* cum = (const int32_t*)be.raw((size_t)B * L * sizeof(int32_t));
+  const float* dur_keep = be.f((size_t)B * L);
   Bump bp(ws_dec, ws_bytes);
   Scratch sc = carve(c, bp, (size_t)B * T, T);
   const long long* lens = (const long long*)mel_lens;
   const int d = c.d_dec, M = B * T;
 
   NS_HIP(launch_mask_from_lengths(lens, B, T, mel_mask, st));
-  NS_HIP(launch_length_regulate(enc_out, cum, B, L, c.d_enc, T, sc.xa, st));
+  if (c.length_regulator == 1) {
+    // extension: GaussianUpsampling (model/modules.py:166-192) in the LengthRegulator's place;
+    // mel_len = sum of the rounded durations, frames past an utterance's own length are zero like pad()'s
+    if ((size_t)B * (L + 1) > (size_t)M * c.vp_filter) return fail("ns_forward_mel: workspace too small for the Gaussian centres");
+    NS_HIP(launch_gaussian_upsampling(enc_out, dur_keep, B, L, c.d_enc, T, T, sc.xa, sc.vp2, nullptr, lens, st));
+  } else {
+    NS_HIP(launch_length_regulate(enc_out, cum, B, L, c.d_enc, T, sc.xa, st));
+  }
   const float* pos;
   NS_TRY(position_rows(m, m->dec_pos, T, d, sc, &pos, st));
-  // frame-level pitch then energy (model/modules.py:139-149); the decoder's position add rides on the second one
-  NS_TRY(predictor(m, m->pred[1], sc.xa, lens, B, T, p_control, p_targets, p_pred, m->P(m->pitch_bins), m->P(m->pitch_emb), nullptr,
-                   sc.xb, sc, st));
-  NS_TRY(predictor(m, m->pred[2], sc.xb, lens, B, T, e_control, e_targets, e_pred, m->P(m->energy_bins), m->P(m->energy_emb), pos,
-                   sc.xa, sc, st));
+  // frame-level pitch then energy (model/modules.py:139-149); MelDecoder's position add rides on the last
+  // frame-level embedding kernel (or is a kernel of its own when both features are phoneme_level)
+  float* cur = sc.xa;
+  float* alt = sc.xb;
+  if (c.pitch_frame_level) {
+    if (!p_pred) return fail("ns_forward_mel: frame_level pitch needs a p_pred [B,T] output");
+    NS_TRY(predictor(m, m->pred[1], cur, lens, B, T, p_control, p_targets, p_pred, m->P(m->pitch_bins), m->P(m->pitch_emb),
+                     c.energy_frame_level ? nullptr : pos, alt, sc, st));
+    float* t = cur; cur = alt; alt = t;
+  }
+  if (c.energy_frame_level) {
+    if (!e_pred) return fail("ns_forward_mel: frame_level energy needs an e_pred [B,T] output");
+    NS_TRY(predictor(m, m->pred[2], cur, lens, B, T, e_control, e_targets, e_pred, m->P(m->energy_bins), m->P(m->energy_emb), pos,
+                     alt, sc, st));
+    float* t = cur; cur = alt; alt = t;
+  }
+  if (!c.pitch_frame_level && !c.energy_frame_level) {
+    NS_HIP(launch_add_pos(cur, pos, alt, M, T, d, st));
+    float* t = cur; cur = alt; alt = t;
+  }
   m->prof_active = m->prof;  // time only the decoder stack's launches: one shape, [B*T, k*d] x [k*d, d_inner]
-  const int rc_dec = decoder_stack(m, sc.xa, lens, B, T, sc.att, sc, st);
+  const int rc_dec = decoder_stack(m, cur, lens, B, T, sc.att, sc, st);
   m->prof_active = false;
   NS_TRY(rc_dec);
   // note: decoder_stack's last layer writes into sc.att only after its own attention output was consumed
@@ -677,7 +715,7 @@ extern "C" int ns_op_gaussian_upsampling(const float* x, const float* durations,
                                          float* s, float* w, void* stream) {
   if (T_out < T) return fail("ns_op_gaussian_upsampling: T_out < T");
   if ((size_t)L * sizeof(float) > 60000) return fail("ns_op_gaussian_upsampling: L too large");
-  NS_HIP(launch_gaussian_upsampling(x, durations, B, L, D, T, T_out, out, s, w, (hipStream_t)stream));
+  NS_HIP(launch_gaussian_upsampling(x, durations, B, L, D, T, T_out, out, s, w, nullptr, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ns_op_mel_decoder(ns_model* m, const float* x, const int64_t* lens, int B, int T, float* out, void* ws,

@@ -47,6 +47,6 @@ hipError_t launch_duration_round(const float* log_d, int n, float d_control, flo
 hipError_t launch_duration_scan(const float* d_rounded, int B, int L, int32_t* cum, long long* mel_lens, hipStream_t st);
 hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int L, int D, int T, float* out, hipStream_t st);
 hipError_t launch_gaussian_upsampling(const float* x, const float* dur, int B, int L, int D, int T, int T_out,
-                                      float* out, float* s, float* w, hipStream_t st);
+                                      float* out, float* s, float* w, const long long* own_len, hipStream_t st);
 
 }  // namespace ns

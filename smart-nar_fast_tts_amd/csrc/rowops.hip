@@ -346,12 +346,14 @@ __global__ __launch_bounds__(256) void k_gauss_centers(const float* __restrict__
 }
 __global__ __launch_bounds__(256) void k_gauss_upsample(const float* __restrict__ x, const float* __restrict__ centers, int L,
                                                          int D, int T, int T_out, float* __restrict__ out,
-                                                         float* __restrict__ w) {
+                                                         float* __restrict__ w, const long long* __restrict__ own_len) {
   extern __shared__ float wl[];  // [L]
   __shared__ float red[4];
   const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   float* orow = out + ((size_t)b * T_out + t) * D;
-  if (t >= T) {
+  // own_len == nullptr: the reference module's behaviour (frames past an utterance's own length are NOT zeroed);
+  // own_len given: the wired-in length regulator zero-pads them like LengthRegulator + pad() does
+  if (t >= T || (own_len && (long long)t >= own_len[b])) {
     for (int c = tid; c < D; c += 256) orow[c] = 0.f;
     return;
   }
@@ -379,13 +381,13 @@ __global__ __launch_bounds__(256) void k_gauss_upsample(const float* __restrict_
   }
 }
 hipError_t launch_gaussian_upsampling(const float* x, const float* dur, int B, int L, int D, int T, int T_out, float* out,
-                                      float* s, float* w, hipStream_t st) {
+                                      float* s, float* w, const long long* own_len, hipStream_t st) {
   if (B <= 0 || T_out <= 0) return hipSuccess;
-  // centers are staged in the head of `out`'s tail? no: use the w buffer's caller-provided scratch is not available,
-  // so centers live in a small device-side region carved from `s`: s must have room for B + B*L floats.
+  // s holds B sums followed by B*L Gaussian centres (scratch)
   float* centers = s + B;
   hipLaunchKernelGGL(k_gauss_centers, dim3(B), dim3(64), 0, st, dur, L, centers, s);
-  hipLaunchKernelGGL(k_gauss_upsample, dim3(T_out, B), dim3(256), L * sizeof(float), st, x, centers, L, D, T, T_out, out, w);
+  hipLaunchKernelGGL(k_gauss_upsample, dim3(T_out, B), dim3(256), L * sizeof(float), st, x, centers, L, D, T, T_out, out, w,
+                     own_len);
   return hipGetLastError();
 }
 

@@ -39,6 +39,9 @@ def config_struct(preprocess_config: dict, model_config: dict) -> _lib.NsConfig:
         postnet_dim=wl.POSTNET_DIM, postnet_k=wl.POSTNET_K, postnet_n=wl.POSTNET_N,
         pitch_frame_level=int(pp["pitch"]["feature"] == "frame_level"),
         energy_frame_level=int(pp["energy"]["feature"] == "frame_level"),
+        # EXTENSION key (absent from the reference's model.yaml): "gaussian" wires the reference's unused
+        # GaussianUpsampling module in place of the hard LengthRegulator
+        length_regulator={"hard": 0, "gaussian": 1}[model_config.get("length_regulator", "hard")],
     )
 
 
@@ -203,9 +206,25 @@ class FastSpeech2Align:
             out_mel_lens = torch.empty(B, dtype=torch.long, device=dev)
             ws_enc_bytes = lib.ns_encoder_ws_bytes(self._h, B, L)
             ws_enc = self._workspace("enc", ws_enc_bytes)
-            _lib.check(lib.ns_forward_durations(self._h, _lib.ptr(texts_c), _lib.ptr(lens_c), B, L, 1.0,
-                                                _lib.ptr(ws_enc), ws_enc.numel(), _lib.ptr(log_d), _lib.ptr(d_rounded),
-                                                _lib.ptr(src_masks), _lib.ptr(out_mel_lens), st), "ns_forward_durations")
+            # a phoneme_level feature is predicted on the encoder output ([B,L], model/modules.py:117-126),
+            # a frame_level one after the length regulator ([B,T], :139-149)
+            p_frame, e_frame = bool(self._cfg.pitch_frame_level), bool(self._cfg.energy_frame_level)
+
+            def target(name, t, shape):
+                if t is None:
+                    return None
+                if tuple(t.shape) != shape:
+                    raise ValueError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
+                return t.to(device=dev, dtype=torch.float32).contiguous()
+
+            p_pred = None if p_frame else torch.empty(B, L, **f32)
+            e_pred = None if e_frame else torch.empty(B, L, **f32)
+            _lib.check(lib.ns_forward_durations(
+                self._h, _lib.ptr(texts_c), _lib.ptr(lens_c), B, L, 1.0, float(p_control), float(e_control),
+                _lib.ptr(None if p_frame else target("p_targets", p_targets, (B, L))),
+                _lib.ptr(None if e_frame else target("e_targets", e_targets, (B, L))),
+                _lib.ptr(ws_enc), ws_enc.numel(), _lib.ptr(log_d), _lib.ptr(d_rounded), _lib.ptr(src_masks),
+                _lib.ptr(out_mel_lens), _lib.ptr(p_pred), _lib.ptr(e_pred), st), "ns_forward_durations")
             # the one device->host read: output shapes depend on max(mel_len)
             # (the reference syncs here too: utils/tools.py:92, plus B*L .item() calls at model/modules.py:222)
             if callable(max_mel_len):
@@ -219,23 +238,21 @@ class FastSpeech2Align:
             n_mel = self._cfg.n_mel
             mel = torch.empty(B, T, n_mel, **f32)
             post = torch.empty(B, T, n_mel, **f32)
-            p_pred = torch.empty(B, T, **f32)
-            e_pred = torch.empty(B, T, **f32)
+            if p_frame:
+                p_pred = torch.empty(B, T, **f32)
+            if e_frame:
+                e_pred = torch.empty(B, T, **f32)
             mel_masks = torch.empty(B, T, dtype=torch.bool, device=dev)
-            tg = []
-            for name, t in (("p_targets", p_targets), ("e_targets", e_targets)):
-                # forward() hands p_targets / e_targets to the variance adaptor in the inference branch too
-                # (model/fastspeech2_align.py:70-78): the embedding then comes from bucketize(target)
-                if t is not None:
-                    if tuple(t.shape) != (B, T):
-                        raise ValueError(f"{name} must have shape {(B, T)}, got {tuple(t.shape)}")
-                    t = t.to(device=dev, dtype=torch.float32).contiguous()
-                tg.append(t)
+            # forward() hands p_targets / e_targets to the variance adaptor in the inference branch too
+            # (model/fastspeech2_align.py:70-78): the embedding then comes from bucketize(target)
+            tg = [target("p_targets", p_targets, (B, T)) if p_frame else None,
+                  target("e_targets", e_targets, (B, T)) if e_frame else None]
             if T > 0:
                 ws_dec_bytes = lib.ns_decoder_ws_bytes(self._h, B, L, T)
                 ws_dec = self._workspace("dec", ws_dec_bytes)
                 _lib.check(lib.ns_forward_mel(self._h, B, L, T, _lib.ptr(out_mel_lens), float(p_control), float(e_control),
                                               _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(ws_enc), _lib.ptr(ws_dec), ws_dec.numel(), _lib.ptr(mel),
-                                              _lib.ptr(post), _lib.ptr(p_pred), _lib.ptr(e_pred), _lib.ptr(mel_masks), st),
+                                              _lib.ptr(post), _lib.ptr(p_pred if p_frame else None),
+                                              _lib.ptr(e_pred if e_frame else None), _lib.ptr(mel_masks), st),
                            "ns_forward_mel")
         return (mel, post, p_pred, e_pred, log_d, d_rounded, src_masks, mel_masks, src_lens, out_mel_lens, None, None)

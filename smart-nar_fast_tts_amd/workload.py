@@ -86,8 +86,12 @@ def model_config(name: str = "ljspeech") -> dict:
     raise KeyError(name)
 
 
-def preprocess_config() -> dict:
-    return copy.deepcopy(LJSPEECH_PREPROCESS_CONFIG)
+def preprocess_config(pitch: str = "frame_level", energy: str = "frame_level") -> dict:
+    """preprocess.yaml restated; ``pitch`` / ``energy`` select the feature level (model/modules.py:26-33)."""
+    pc = copy.deepcopy(LJSPEECH_PREPROCESS_CONFIG)
+    pc["preprocessing"]["pitch"]["feature"] = pitch
+    pc["preprocessing"]["energy"]["feature"] = energy
+    return pc
 
 
 def sinusoid_table(n_position: int, d_hid: int) -> np.ndarray:

@@ -41,10 +41,10 @@ import smart_nar_fast_tts_amd.workload as wl  # noqa: E402
 torch.set_num_threads(8)
 
 
-def build_reference(model_cfg, sd_np):
+def build_reference(model_cfg, sd_np, pitch="frame_level", energy="frame_level"):
     from model.fastspeech2_align import FastSpeech2Align  # the reference class
 
-    pc = wl.preprocess_config()
+    pc = wl.preprocess_config(pitch, energy)
     d = tempfile.mkdtemp()
     with open(os.path.join(d, "stats.json"), "w") as f:
         json.dump(wl.SYNTH_STATS, f)
@@ -64,7 +64,8 @@ def edge_distance(v, bins):
     return np.minimum(np.abs(v - bins[i - 1]), np.abs(bins[i] - v)).astype(np.float32)
 
 
-def run_case(model, speakers, texts, src_lens, max_src_len, hooks=None, p_targets=None, e_targets=None):
+def run_case(model, speakers, texts, src_lens, max_src_len, hooks=None, p_targets=None, e_targets=None,
+             p_control=1.0, e_control=1.0):
     cap = {}
     handles = []
     if hooks:
@@ -84,7 +85,8 @@ def run_case(model, speakers, texts, src_lens, max_src_len, hooks=None, p_target
     with torch.no_grad():
         out = model(torch.from_numpy(speakers), torch.from_numpy(texts), torch.from_numpy(src_lens), max_src_len,
                     p_targets=None if p_targets is None else torch.from_numpy(p_targets),
-                    e_targets=None if e_targets is None else torch.from_numpy(e_targets))
+                    e_targets=None if e_targets is None else torch.from_numpy(e_targets),
+                    p_control=p_control, e_control=e_control)
     for h in handles:
         h.remove()
     names = ["output", "postnet_output", "p_predictions", "e_predictions", "log_d_predictions", "d_rounded",
@@ -305,8 +307,75 @@ def kat_cases():
          x=gx, d=gd, out=go.numpy(), s=gs.numpy(), w=gw.numpy(), out_maxlen40=go2.numpy())
 
 
+def edge_ok(res, mask_key, margin=PE_MARGIN):
+    v = ~res[mask_key]
+    return all(res[k][v].min() > margin for k in ("p_edge_rel", "e_edge_rel") if res[k].shape == v.shape)
+
+
+def feature_level_cases():
+    """§8 f4: phoneme_level pitch / energy (model/modules.py:117-126), both and mixed with frame_level."""
+    cfg = wl.model_config("tiny")
+    sd = wl.synth_state_dict(cfg, seed=0, frames_per_phoneme=4.0)
+    for name, pl, el in (("e2e_tiny_phoneme_level", "phoneme_level", "phoneme_level"),
+                         ("e2e_tiny_pitch_phoneme_energy_frame", "phoneme_level", "frame_level"),
+                         ("e2e_tiny_pitch_frame_energy_phoneme", "frame_level", "phoneme_level")):
+        model = build_reference(cfg, sd, pl, el)
+        B, L, lens = 3, 20, [20, 13, 7]
+        for seed in range(400):
+            inp = wl.synth_inputs(B, L, seed=seed, src_lens=lens)
+            res, _ = run_case(model, *inp, p_control=1.2, e_control=0.9)
+            ok = res["half_dist"][~res["src_masks"]].min() > 2e-3
+            for key, lvl in (("p_edge_rel", pl), ("e_edge_rel", el)):
+                m = ~(res["src_masks"] if lvl == "phoneme_level" else res["mel_masks"])
+                ok = ok and res[key][m].min() > PE_MARGIN
+            if ok:
+                break
+        else:
+            raise RuntimeError("no seed with margin")
+        meta = dict(config="tiny", weight_seed=0, frames_per_phoneme=4.0, dur_weight_scale=0.25, input_seed=seed, B=B, L=L,
+                    src_lens=lens, pitch_level=pl, energy_level=el, p_control=1.2, e_control=0.9)
+        save(name, meta, speakers=inp[0], texts=inp[1], in_src_lens=inp[2], **res)
+
+
+def gaussian_wired_case():
+    """§8 f1 (an extension beyond reference behaviour): the reference's own GaussianUpsampling module
+    (model/modules.py:162-192) put where VarianceAdaptor instantiates LengthRegulator (:22), mel_len = sum of durations,
+    frames past an utterance's own length zeroed like the hard regulator's padding.  Generated with the reference's
+    modules; only the three wiring lines below are ours."""
+    import model.modules as mm
+    mm.device = torch.device("cpu")
+    cfg = wl.model_config("tiny")
+    sd = wl.synth_state_dict(cfg, seed=0, frames_per_phoneme=4.0)
+    model = build_reference(cfg, sd)
+    gu = mm.GaussianUpsampling()
+
+    class Wired(torch.nn.Module):
+        def forward(self, x, duration, max_len):
+            out, s, _ = gu(x, duration, torch.ones_like(duration), max_len)
+            mel_len = s.reshape(-1).long()
+            pad = torch.arange(out.shape[1])[None, :] >= mel_len[:, None]
+            return out.masked_fill(pad.unsqueeze(-1), 0.0), mel_len
+
+    model.variance_adaptor.length_regulator = Wired()
+    B, L, lens = 3, 20, [20, 13, 7]
+    for seed in range(400):
+        inp = wl.synth_inputs(B, L, seed=seed, src_lens=lens)
+        res, _ = run_case(model, *inp)
+        if res["half_dist"][~res["src_masks"]].min() > 2e-3 and pe_margin_ok(res):
+            break
+    else:
+        raise RuntimeError("no seed with margin")
+    meta = dict(config="tiny", weight_seed=0, frames_per_phoneme=4.0, dur_weight_scale=0.25, input_seed=seed, B=B, L=L,
+                src_lens=lens, length_regulator="gaussian")
+    save("e2e_tiny_gaussian_wired", meta, speakers=inp[0], texts=inp[1], in_src_lens=inp[2], **res)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["e2e", "neighbour", "pos", "kat", "pins"]
+    which = sys.argv[1:] or ["e2e", "neighbour", "pos", "kat", "pins", "levels", "gaussian"]
+    if "levels" in which:
+        feature_level_cases()
+    if "gaussian" in which:
+        gaussian_wired_case()
     if "kat" in which:
         kat_cases()
     if "e2e" in which:

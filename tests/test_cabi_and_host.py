@@ -57,8 +57,7 @@ def test_create_validates_config(lib):
     assert so.ns_arena_bytes(h) > 30e6
     so.ns_destroy(h)
     for over, msg in ((dict(n_enc_head=3), "divisible"), (dict(n_dec_head=16), "d_k"), (dict(ffn_k1=8), "odd"),
-                      (dict(vp_kernel=5), "padding=1"), (dict(pitch_frame_level=0), "phoneme_level"),
-                      (dict(d_dec=512), "encoder_hidden")):
+                      (dict(vp_kernel=5), "padding=1"), (dict(d_dec=512), "encoder_hidden")):
         assert so.ns_create(C.byref(_cfg(L, **over)), C.byref(h)) != 0
         assert msg in so.ns_last_error().decode(), (over, so.ns_last_error())
 
@@ -89,7 +88,8 @@ def test_forward_refuses_without_weights(lib):
     L, so = lib
     h = C.c_void_p()
     assert so.ns_create(C.byref(_cfg(L)), C.byref(h)) == 0
-    rc = so.ns_forward_durations(h, None, None, 1, 4, 1.0, None, 0, None, None, None, None, None)
+    rc = so.ns_forward_durations(h, None, None, 1, 4, 1.0, 1.0, 1.0, None, None, None, 0, None, None, None, None, None, None,
+                                 None)
     assert rc != 0 and "weights not loaded" in so.ns_last_error().decode()
     so.ns_destroy(h)
 

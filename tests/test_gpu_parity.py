@@ -360,3 +360,30 @@ def test_errors_are_loud():
         m.load_state_dict(bad)
     with pytest.raises(RuntimeError, match="cuda"):
         FastSpeech2Align(wl.preprocess_config(), cfg).to("cpu")
+
+
+def gpu_model_for(meta):
+    """Like gpu_model, for fixtures that also choose feature levels / the length regulator."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    cfg, sd = weights_for(meta)
+    cfg = dict(cfg, length_regulator=meta.get("length_regulator", "hard"))
+    pc = wl.preprocess_config(meta.get("pitch_level", "frame_level"), meta.get("energy_level", "frame_level"))
+    m = FastSpeech2Align(pc, cfg).to("cuda").eval()
+    m.load_state_dict(sd)
+    return cfg, sd, m
+
+
+@pytest.mark.parametrize("name", ["e2e_tiny_phoneme_level", "e2e_tiny_pitch_phoneme_energy_frame",
+                                  "e2e_tiny_pitch_frame_energy_phoneme", "e2e_tiny_gaussian_wired"])
+def test_feature_levels_and_gaussian_regulator(name):
+    """§8 f4: phoneme_level pitch/energy (predicted on the encoder output, [B,L] predictions) in all three mixes, with
+    p/e_control != 1; §8 f1: the reference's GaussianUpsampling module wired in as the length regulator (extension)."""
+    meta, z = load_golden(name)
+    cfg, sd, m = gpu_model_for(meta)
+    with torch.no_grad():
+        out = m(dev(z["speakers"]), dev(z["texts"]), dev(z["in_src_lens"]), int(meta["L"]),
+                p_control=meta.get("p_control", 1.0), e_control=meta.get("e_control", 1.0))
+    torch.cuda.synchronize()
+    print(name, check_12tuple(out, z))

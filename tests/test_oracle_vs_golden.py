@@ -182,3 +182,27 @@ def test_baseline_size_pins(name):
     st = meta["frame_stride"]
     assert np.abs(out[0].numpy()[:, ::st] - z["output_sub"]).max() <= 1e-4
     assert np.abs(out[1].numpy()[:, ::st] - z["postnet_output_sub"]).max() <= 1e-4
+
+
+LEVEL_CASES = ["e2e_tiny_phoneme_level", "e2e_tiny_pitch_phoneme_energy_frame", "e2e_tiny_pitch_frame_energy_phoneme",
+               "e2e_tiny_gaussian_wired"]
+
+
+@pytest.mark.parametrize("name", LEVEL_CASES)
+def test_feature_levels_and_gaussian_regulator(name):
+    """§8 f4 (phoneme_level pitch/energy, model/modules.py:117-126) and §8 f1 (GaussianUpsampling wired in, an extension)."""
+    meta, z = load_golden(name)
+    cfg, sd = weights_for(meta)
+    with torch.no_grad():
+        out = orc.forward(orc.to_torch_weights(sd), cfg, torch.from_numpy(z["speakers"]), torch.from_numpy(z["texts"]),
+                          torch.from_numpy(z["in_src_lens"]), int(meta["L"]),
+                          p_control=meta.get("p_control", 1.0), e_control=meta.get("e_control", 1.0),
+                          pitch_level=meta.get("pitch_level", "frame_level"), energy_level=meta.get("energy_level", "frame_level"),
+                          length_regulator=meta.get("length_regulator", "hard"))
+    for i, n in enumerate(NAMES):
+        got, ref = out[i].numpy(), z[n]
+        assert got.shape == ref.shape and got.dtype == ref.dtype, (n, got.shape, ref.shape)
+        if got.dtype == np.float32:
+            assert np.abs(got - ref).max() <= TOL * max(1.0, np.abs(ref).max() / 50), (n, np.abs(got - ref).max())
+        else:
+            assert np.array_equal(got, ref), n
