@@ -1,0 +1,104 @@
+"""The steps either side of the forward: building a batch from phoneme-id arrays and slicing
+the padded outputs back into per-utterance results.  Host-side numpy/torch plumbing, restated from
+
+* ``TextDataset.collate_fn``  dataset.py:182-191     -> :func:`collate`
+* ``pad_1D``                  utils/tools.py:254-264  -> :func:`pad_1D`
+* ``to_device`` (6-tuple)     utils/tools.py:56-63    -> :func:`to_device`
+* ``synthesize``              synthesize.py:59-76     -> :func:`synthesize` (forward only: no plots, no vocoder)
+* per-utterance slicing       utils/tools.py:153-171  -> :func:`split_outputs`
+* ``expand``                  utils/tools.py:100-104  -> :func:`expand`
+
+plus one extension, :func:`bucket_by_length`: batches of similar phoneme length, which cuts padded work and the
+batch-composition effects of SURVEY.md F3.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def pad_1D(inputs, PAD: int = 0) -> np.ndarray:
+    """Right-pad 1-D arrays with PAD to the longest (utils/tools.py:254-264)."""
+    max_len = max(len(x) for x in inputs)
+    return np.stack([np.pad(x, (0, max_len - x.shape[0]), mode="constant", constant_values=PAD) for x in inputs])
+
+
+def collate(data):
+    """``data``: list of (basename, speaker_id, phoneme_ids ndarray, raw_text) as TextDataset.__getitem__ yields them
+    (dataset.py:157-164).  Returns (ids, raw_texts, speakers, texts, text_lens, max_text_len) (dataset.py:182-191)."""
+    ids = [d[0] for d in data]
+    speakers = np.array([d[1] for d in data])
+    texts = [np.asarray(d[2]) for d in data]
+    raw_texts = [d[3] for d in data]
+    text_lens = np.array([t.shape[0] for t in texts])
+    return ids, raw_texts, speakers, pad_1D(texts), text_lens, max(text_lens)
+
+
+def to_device(data, device):
+    """The 6-tuple branch of utils/tools.py:56-63: numpy -> torch on ``device``; ids / raw_texts / max_len pass through."""
+    ids, raw_texts, speakers, texts, src_lens, max_src_len = data
+    speakers = torch.from_numpy(np.asarray(speakers)).long().to(device)
+    texts = torch.from_numpy(np.asarray(texts)).long().to(device)
+    src_lens = torch.from_numpy(np.asarray(src_lens)).to(device)
+    return ids, raw_texts, speakers, texts, src_lens, max_src_len
+
+
+def expand(values, durations) -> np.ndarray:
+    """Repeat values[i] max(0, int(durations[i])) times (utils/tools.py:100-104)."""
+    out = []
+    for value, d in zip(values, durations):
+        out += [value] * max(0, int(d))
+    return np.array(out)
+
+
+def split_outputs(batch, predictions, preprocess_config):
+    """Per-utterance slices of forward()'s 12-tuple, the tensor part of synth_samples (utils/tools.py:153-171):
+    mel [mel_len, n_mel] (the reference transposes it for plotting; the time-major slice is returned here),
+    duration [src_len], pitch / energy at frame rate (phoneme_level predictions are expanded by the durations)."""
+    pp = preprocess_config["preprocessing"]
+    src_lens = predictions[8].cpu().tolist()
+    mel_lens = predictions[9].cpu().tolist()
+    out = []
+    for i, basename in enumerate(batch[0]):
+        src_len, mel_len = int(src_lens[i]), int(mel_lens[i])
+        duration = predictions[5][i, :src_len].detach().cpu().numpy()
+        item = {"basename": basename, "mel": predictions[1][i, :mel_len].detach(), "duration": duration,
+                "src_len": src_len, "mel_len": mel_len}
+        for name, idx in (("pitch", 2), ("energy", 3)):
+            if pp[name]["feature"] == "phoneme_level":
+                item[name] = expand(predictions[idx][i, :src_len].detach().cpu().numpy(), duration)
+            else:
+                item[name] = predictions[idx][i, :mel_len].detach().cpu().numpy()
+        out.append(item)
+    return out
+
+
+def synthesize(model, batchs, preprocess_config, device="cuda", p_control: float = 1.0, e_control: float = 1.0):
+    """synthesize.py:59-76 reduced to its tensor contract: to_device -> model(*(batch[2:])) under no_grad ->
+    per-utterance results (what synth_samples would plot / vocode)."""
+    results = []
+    for batch in batchs:
+        batch = to_device(batch, device)
+        with torch.no_grad():
+            output = model(*(batch[2:]), p_control=p_control, e_control=e_control)
+        results.extend(split_outputs(batch, output, preprocess_config))
+    return results
+
+
+def bucket_by_length(lengths, max_batch: int, max_pad_fraction: float = 0.1):
+    """EXTENSION (not in the reference): group utterance indices into batches of similar length.
+
+    Sorted by length, a batch is closed when it holds ``max_batch`` items or when admitting the next item would make
+    the shortest member's padding exceed ``max_pad_fraction`` of the batch's max length.  Every index appears once."""
+    order = np.argsort(np.asarray(lengths), kind="stable")[::-1]
+    batches, cur = [], []
+    for idx in order:
+        if cur:
+            longest = lengths[cur[0]]
+            if len(cur) >= max_batch or (longest - lengths[idx]) > max_pad_fraction * longest:
+                batches.append(cur)
+                cur = []
+        cur.append(int(idx))
+    if cur:
+        batches.append(cur)
+    return batches

@@ -370,8 +370,27 @@ def gaussian_wired_case():
     save("e2e_tiny_gaussian_wired", meta, speakers=inp[0], texts=inp[1], in_src_lens=inp[2], **res)
 
 
+def batching_case():
+    """§8 f2: TextDataset.collate_fn (dataset.py:182-191), pad_1D (utils/tools.py:254-264), expand (:100-104)."""
+    from dataset import TextDataset
+    from utils.tools import expand, pad_1D
+
+    rs = np.random.RandomState(9)
+    lens = [7, 19, 1, 12, 19]
+    data = [(f"utt{i}", i % 3, rs.randint(1, 361, size=n).astype(np.int64), f"raw text {i}") for i, n in enumerate(lens)]
+    ids, raw_texts, speakers, texts, text_lens, max_len = TextDataset.collate_fn(None, data)
+    vals = rs.standard_normal(6).astype(np.float32)
+    durs = np.array([2.0, 0.0, -0.0, 3.9, -1.0, 1.0], dtype=np.float32)
+    save("kat_batching", dict(ids=ids, raw_texts=raw_texts, max_len=int(max_len)),
+         phones=np.concatenate([d[2] for d in data]), phone_lens=np.array(lens), speaker_ids=np.array([d[1] for d in data]),
+         speakers=speakers, texts=texts, text_lens=text_lens, pad1d=pad_1D([d[2] for d in data], 5),
+         expand_vals=vals, expand_durs=durs, expand_out=expand(vals, durs))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["e2e", "neighbour", "pos", "kat", "pins", "levels", "gaussian"]
+    which = sys.argv[1:] or ["batching", "e2e", "neighbour", "pos", "kat", "pins", "levels", "gaussian"]
+    if "batching" in which:
+        batching_case()
     if "levels" in which:
         feature_level_cases()
     if "gaussian" in which:

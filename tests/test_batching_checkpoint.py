@@ -1,0 +1,98 @@
+"""§8 f2 (batch construction / output slicing) and §8 f3 (checkpoint reader): host-side logic on CPU, plus a GPU
+round trip through a checkpoint file."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import load_golden
+
+
+def _data(z, meta):
+    off = np.concatenate([[0], np.cumsum(z["phone_lens"])])
+    return [(meta["ids"][i], int(z["speaker_ids"][i]), z["phones"][off[i]:off[i + 1]], meta["raw_texts"][i])
+            for i in range(len(meta["ids"]))]
+
+
+def test_collate_pad_expand_match_reference():
+    from smart_nar_fast_tts_amd import batching
+
+    meta, z = load_golden("kat_batching")
+    ids, raw_texts, speakers, texts, text_lens, max_len = batching.collate(_data(z, meta))
+    assert ids == meta["ids"] and raw_texts == meta["raw_texts"] and int(max_len) == meta["max_len"]
+    for got, key in ((speakers, "speakers"), (texts, "texts"), (text_lens, "text_lens")):
+        assert got.dtype == z[key].dtype and np.array_equal(got, z[key]), key
+    assert np.array_equal(batching.pad_1D([d[2] for d in _data(z, meta)], 5), z["pad1d"])
+    assert np.array_equal(batching.expand(z["expand_vals"], z["expand_durs"]), z["expand_out"])
+    dev = batching.to_device((ids, raw_texts, speakers, texts, text_lens, max_len), "cpu")
+    assert dev[2].dtype == torch.long and dev[3].dtype == torch.long and dev[3].shape == (5, 19) and dev[5] == max_len
+
+
+def test_bucket_by_length_partitions():
+    from smart_nar_fast_tts_amd.batching import bucket_by_length
+
+    rs = np.random.RandomState(0)
+    lens = rs.randint(5, 200, size=97).tolist()
+    for max_batch, frac in ((16, 0.1), (4, 0.0), (128, 1.0)):
+        b = bucket_by_length(lens, max_batch, frac)
+        assert sorted(i for g in b for i in g) == list(range(97))
+        for g in b:
+            assert 1 <= len(g) <= max_batch
+            longest = max(lens[i] for i in g)
+            assert all(longest - lens[i] <= frac * longest for i in g)
+    assert len(bucket_by_length(lens, 128, 1.0)) == 1
+
+
+def test_inference_state_dict_filters_training_state():
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd.checkpoint import inference_state_dict
+
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in wl.synth_state_dict(wl.model_config("tiny")).items()}
+    full = dict(sd)
+    full["mel_encoder.prenet.w_1.weight"] = torch.zeros(256, 80)
+    full["mel_encoder.layer_stack.0.crs_attn.w_qs.weight"] = torch.zeros(256, 256)
+    ckpt = {"model": {("module." + k): v for k, v in full.items()}, "optimizer": {"state": {}, "param_groups": []}}
+    got = inference_state_dict(ckpt)
+    assert set(got) == {k for k in sd if not k.endswith("num_batches_tracked")}
+    assert all(torch.equal(got[k], sd[k]) for k in got)
+
+
+@pytest.mark.gpu
+def test_checkpoint_file_round_trip_and_synthesize(tmp_path):
+    """A {step}.pth.tar written the way train.py:149-159 writes it -> get_model -> synthesize() gives the same
+    per-utterance mels as loading the state dict directly; phoneme_level predictions are expanded to frame rate."""
+    import types
+
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd import batching
+    from smart_nar_fast_tts_amd.checkpoint import get_model
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    cfg = wl.model_config("tiny")
+    pc = wl.preprocess_config("phoneme_level", "frame_level")
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in wl.synth_state_dict(cfg, frames_per_phoneme=4.0).items()}
+    ckpt = {"model": dict(sd, **{"mel_encoder.prenet.w_1.weight": torch.zeros(256, 80)}), "optimizer": {"state": {}}}
+    os.makedirs(tmp_path / "ckpt")
+    torch.save(ckpt, tmp_path / "ckpt" / "1000.pth.tar")
+    args = types.SimpleNamespace(restore_step=1000)
+    model = get_model(args, (pc, cfg, {"path": {"ckpt_path": str(tmp_path / "ckpt")}}), torch.device("cuda"))
+    direct = FastSpeech2Align(pc, cfg).to("cuda").eval()
+    direct.load_state_dict(sd)
+
+    meta, z = load_golden("kat_batching")
+    data = _data(z, meta)
+    batchs = [batching.collate([data[i] for i in g]) for g in batching.bucket_by_length(z["phone_lens"].tolist(), 3, 0.5)]
+    res = batching.synthesize(model, batchs, pc, "cuda")
+    assert sorted(r["basename"] for r in res) == sorted(meta["ids"])
+    for r in res:
+        i = meta["ids"].index(r["basename"])
+        assert r["src_len"] == int(z["phone_lens"][i]) and tuple(r["mel"].shape) == (r["mel_len"], 80)
+        assert r["duration"].shape == (r["src_len"],) and int(np.maximum(r["duration"], 0).sum()) == r["mel_len"]
+        assert r["pitch"].shape == (r["mel_len"],) and r["energy"].shape == (r["mel_len"],)
+    # same batch through the directly loaded model: identical bits (same kernels, same weights)
+    b0 = batching.to_device(batchs[0], "cuda")
+    with torch.no_grad():
+        o1, o2 = model(*b0[2:]), direct(*b0[2:])
+    assert torch.equal(o1[1], o2[1]) and torch.equal(o1[9], o2[9])
