@@ -92,11 +92,12 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)&Vd[(wid * NI + i) * RPI * DK], 16, vv[i] + kt * tile_step, 0, 0, 0);
   };
 
-  // Q^T operand: lane (q, h) keeps Q[q][8g + 4h + e]
+  // Q^T operand: lane (q, h) keeps Q[q][8g + 4h + e], pre-multiplied by log2(e)/sqrt(d_k) so the scores come out
+  // of the MFMA already scaled into the exp2 domain (one multiply per Q element instead of one per score)
   f32x4 qreg[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    if (q < S) qreg[g] = *reinterpret_cast<const f32x4*>(base + (size_t)q * ld + 8 * g + 4 * h);
+    if (q < S) qreg[g] = *reinterpret_cast<const f32x4*>(base + (size_t)q * ld + 8 * g + 4 * h) * c_scale;
     else qreg[g] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
@@ -126,16 +127,19 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
       for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qreg[g][e], s, 0, 0, 0);
     }
   };
-  // scale (log2 domain), key-padding mask, online softmax of tile kt; s becomes P, returns the O rescale factor
+  // key-padding mask + online softmax of tile kt; s becomes P, returns the O rescale factor
   auto softmax_tile = [&](int kt, f32x16& s) -> float {
-    const int kbase = kt * BC + 4 * h;
+    if (kt * BC + BC > len) {  // wave-uniform: only the tile that straddles lens[b] needs the per-key compare
+      const int kbase = kt * BC + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kbase + (r & 3) + 8 * (r >> 2);
+        s[r] = key < len ? s[r] : -INFINITY;
+      }
+    }
     float mt = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kbase + (r & 3) + 8 * (r >> 2);
-      s[r] = key < len ? s[r] * c_scale : -INFINITY;
-      mt = fmaxf(mt, s[r]);
-    }
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32));
     // Lazy reference point: softmax is exact for ANY reference m as long as exp2(s - m) cannot overflow, so the
     // running reference only moves when a score exceeds it by more than 2^RESCALE_LOG2 (P stays <= 2^10, far inside
@@ -186,28 +190,32 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   }
   __syncthreads();
 
-  f32x16 s_cur, s_next;
-  if (nkt > 0) qk(Ks0, s_cur);
+  f32x16 s_a, s_b;  // score tiles of even / odd key tiles (static roles in the 2x unrolled loop: no register copies)
+  if (nkt > 0) qk(Ks0, s_a);
   __syncthreads();  // every wave has read K(0) before the loop's first DMA reuses its buffer
 
   // one key tile kt (not the last): K(kt) and V(kt-1) are dead -> refill their buffers with K(kt+2) / V(kt+1);
   // matrix pipe: next tile's scores, VALU: this tile's softmax, then P(kt) V(kt)
-  auto tile = [&](int kt, float* Kdead, const float* Knext, const float* Vcur, float* Vdead) {
+  auto tile = [&](int kt, float* Kdead, const float* Knext, const float* Vcur, float* Vdead, f32x16& s_cur, f32x16& s_next) {
     if (kt + 2 < nkt) dma_k(Kdead, kt + 2);
     dma_v(Vdead, kt + 1);
     qk(Knext, s_next);
     const float alpha = softmax_tile(kt, s_cur);
     pv(Vcur, s_cur, alpha);
-    s_cur = s_next;
     __syncthreads();  // drains the DMA issued above and fences the buffer reuse
   };
   for (int kt = 0; kt + 1 < nkt; kt += 2) {
-    tile(kt, Ks0, Ks1, Vs0, Vs1);
-    if (kt + 2 < nkt) tile(kt + 1, Ks1, Ks0, Vs1, Vs0);
+    tile(kt, Ks0, Ks1, Vs0, Vs1, s_a, s_b);
+    if (kt + 2 < nkt) tile(kt + 1, Ks1, Ks0, Vs1, Vs0, s_b, s_a);
   }
   if (nkt > 0) {
-    const float alpha = softmax_tile(nkt - 1, s_cur);
-    pv(((nkt - 1) & 1) ? Vs1 : Vs0, s_cur, alpha);
+    if ((nkt - 1) & 1) {
+      const float alpha = softmax_tile(nkt - 1, s_b);
+      pv(Vs1, s_b, alpha);
+    } else {
+      const float alpha = softmax_tile(nkt - 1, s_a);
+      pv(Vs0, s_a, alpha);
+    }
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
