@@ -10,20 +10,23 @@
 // kernel window is just the same matrix shifted by (j - pad) rows, zero outside the utterance's [0,S)
 // window.  K runs tap-major (k = j*Cin + c), BK divides Cin, so one K-chunk touches one tap.
 //
-// Tiling (wave64, 4 waves = 2x2 per workgroup): block tile BMxBN, wave tile (BM/2)x(BN/2) as a grid of
-// 32x32 MFMA tiles, K-chunk BK double-buffered in LDS.
+// Tiling (wave64): block tile BMxBN computed by WGM x WGN waves, wave tile (BM/WGM)x(BN/WGN) as a grid of 32x32 MFMA
+// tiles, K-chunk BK double-buffered in LDS.  KS > 1 adds an in-workgroup split of K: KS groups of waves each take
+// every KS-th chunk into their own accumulators and the partial tiles are summed through LDS at the end.  It is
+// used when the output has too few tiles to occupy the chip (the encoder's [B*L, *] GEMMs, single-utterance
+// latency): the serial K loop of a tile, not the matrix pipe, bounds those launches.
 //
 // Staging is LDS-DMA (`buffer_load_dwordx4 ... lds`): operands go HBM/L2 -> LDS without touching VGPRs, the
 // zero padding of the convolution and the M/N tile tails come for free from the buffer descriptor's
 // out-of-range rule (a lane whose voffset is the OOR marker writes zeros to LDS), and the per-chunk cost on the
-// issuing wave is 8 DMA instructions with a scalar offset bump — no address VALU, no ds_write pass, nothing
-// between a chunk's MFMAs but 16 ds_read_b128.  (Measured on the dominant shape: register-staged version
-// 106 TFLOP/s, its compute-only ablation 137; see tools/lab.)
+// issuing wave is a handful of DMA instructions with a scalar offset bump — no address VALU, no ds_write pass.
+// (Measured on the dominant shape: register-staged version 106 TFLOP/s, its compute-only ablation 137; see tools/lab.)
 //
 // The DMA destination is lane-linear (wave-uniform base + lane*16 B), so rows cannot be padded; bank conflicts
 // of the fragment reads are removed by an XOR swizzle applied on the SOURCE side: 16-byte slot s of tile row r
 // holds column chunk c = s ^ f(r), f(r) = (r>>1)&7 for 128-B rows (BK=32), (r>>2)&3 for 64-B rows (BK=16);
-// the reads apply the same XOR.  With it every ds_read_b128 lane group touches 16 distinct 16-B bank slots.
+// the reads apply the same XOR.  With it every ds_read_b128 lane group touches 16 distinct 16-B bank slots
+// (SQ_LDS_BANK_CONFLICT = 0 in profiles/r01_pmc.md).
 //
 // Operand reads use the freedom to permute k identically on both operands: lane-half h of MFMA step e in
 // group g consumes k = 8g + 4h + e, so each lane reads its 4 steps' operands with ONE ds_read_b128.
@@ -37,28 +40,28 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int OOR = (int)0x80000000;  // voffset marker: beyond num_records -> the DMA writes zeros
 
-template <int BM, int BN, int BK>
-__global__ __launch_bounds__(256) void k_conv_gemm(ConvGemm p, int ntn) {
+template <int BM, int BN, int BK, int KS, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, int ntn) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type does not exist in the host pass; it only needs the stub
-  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int NW = WGM * WGN;       // waves per K-split group, arranged WGM x WGN over the block tile
+  constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int CPR = BK / 4;         // 16-B chunks per tile row
   constexpr int RPI = 64 / CPR;       // tile rows one wave-wide DMA instruction fills
-  constexpr int IA = BM / (4 * RPI);  // DMA instructions per wave per chunk, A and B
-  constexpr int IB = BN / (4 * RPI);
+  static_assert(TM >= 1 && TN >= 1 && BM % RPI == 0 && BN % RPI == 0, "tile / wave-grid geometry");
   constexpr int FSH = (BK == 64) ? 0 : (BK == 32) ? 1 : 2;
   constexpr int FMSK = CPR - 1;
   static_assert(BK == 64 || BK == 32 || BK == 16, "BK");
-  static_assert(IA >= 1 && IB >= 1, "tile too small for 4 waves");
+  static_assert(KS == 1 || (KS - 1) * BM * BN <= 2 * KS * BM * BK, "split-K partial tiles must fit the A staging buffers");
 
   // Four DISTINCT LDS objects (not [2][...] arrays) and a 2x unrolled K loop with a static buffer index: hipcc tracks
   // in-flight LDS-DMA per LDS object, so a ds_read from As0 does not wait for a DMA that is filling As1.  With one
   // object per operand it inserted `s_waitcnt vmcnt(..)` in front of the first fragment read of every chunk, exposing
-  // the whole L2/HBM latency of the prefetch it had just issued.
-  __shared__ __attribute__((aligned(16))) float As0[BM * BK];
-  __shared__ __attribute__((aligned(16))) float As1[BM * BK];
-  __shared__ __attribute__((aligned(16))) float Bs0[BN * BK];
-  __shared__ __attribute__((aligned(16))) float Bs1[BN * BK];
+  // the whole L2/HBM latency of the prefetch it had just issued.  (The KS groups index INSIDE each object.)
+  __shared__ __attribute__((aligned(16))) float As0[KS * BM * BK];
+  __shared__ __attribute__((aligned(16))) float As1[KS * BM * BK];
+  __shared__ __attribute__((aligned(16))) float Bs0[KS * BN * BK];
+  __shared__ __attribute__((aligned(16))) float Bs1[KS * BN * BK];
 
   // XCD-aware bijective remap.  Workgroup b runs on XCD b%8 (observed, used for speed only).  Tiles are ordered
   // "super-row by super-row": the M-tiles are split into 8 contiguous groups, and inside a group the order is
@@ -83,8 +86,9 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemm p, int ntn) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wid >> 1) * WM, wn0 = (wid & 1) * WN;
+  const int wall = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wall / NW, wid = wall % NW;  // K-split group, wave inside the WGM x WGN arrangement
+  const int wm0 = (wid / WGN) * WM, wn0 = (wid % WGN) * WN;
 
   const int Kt = p.KW * p.Cin;
   const int cpj = p.Cin / BK;  // chunks per tap
@@ -96,41 +100,48 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemm p, int ntn) {
   const __amdgpu_buffer_rsrc_t rsB =
       __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)n0 * Kt), (short)0, 0x7FFFFFFF, 0x00020000);
 
-  // per-lane DMA geometry: instruction i of this wave fills tile rows (wid*I + i)*RPI + lane/CPR, slot lane%CPR
+  // DMA work list of one chunk: TOTA = BM/RPI wave-wide instructions fill the A tile (RPI rows each), TOTB = BN/RPI the
+  // B tile.  Round k of wave `wid` takes entry k*NW + wid, so the issue cost is spread over all waves of the group.
+  // When NW divides the counts (every shipped configuration's hot path) there is no branch around any DMA: control
+  // flow between the DMAs and the fragment reads makes hipcc's LDS-DMA scoreboard conservative again.
+  constexpr int TOTA = BM / RPI, TOTB = BN / RPI;
+  constexpr int IA = (TOTA + NW - 1) / NW, IB = (TOTB + NW - 1) / NW;
+  constexpr bool A_EVEN = TOTA % NW == 0, B_EVEN = TOTB % NW == 0;
   const int lr = lane / CPR, ls = lane % CPR;
-  int a_row[IA], a_t[IA], a_col[IA];
-  bool a_ok[IA];
+  // entry taken by round i of this wave: a contiguous run per wave when the list divides evenly, strided otherwise
+  auto ea = [&](int i) { return A_EVEN ? wid * IA + i : i * NW + wid; };
+  auto eb = [&](int i) { return B_EVEN ? wid * IB + i : i * NW + wid; };
+  int a_row[IA], a_t[IA], a_col[IA];  // tile row, position inside the utterance (-1: row >= M), swizzled column
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
-    const int r = (wid * IA + i) * RPI + lr;
+    const int r = ea(i) * RPI + lr;
     const int m = m0 + r;
     a_row[i] = r;
-    a_ok[i] = m < p.M;
-    a_t[i] = a_ok[i] ? (m % p.S) : 0;
+    a_t[i] = (m < p.M) ? (m % p.S) : -1;
     a_col[i] = (ls ^ ((r >> FSH) & FMSK)) * 4;
   }
   int vb[IB];
 #pragma unroll
   for (int i = 0; i < IB; ++i) {
-    const int r = (wid * IB + i) * RPI + lr;
+    const int r = eb(i) * RPI + lr;
     vb[i] = (n0 + r < p.N) ? (r * Kt + (ls ^ ((r >> FSH) & FMSK)) * 4) * 4 : OOR;
   }
-  int va[IA];
-  auto set_tap = [&](int j) {
+  // stage chunk ch (tap j = ch / cpj, channel block cc = ch % cpj) of this group into (As, Bs)
+  auto dma_chunk = [&](float* As, float* Bs, int ch) {
+    const int j = ch / cpj, cc = ch - j * cpj;
+    const int soA = cc * BK * 4, soB = ch * BK * 4;
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
       const int ts = a_t[i] + j - p.pad;
-      va[i] = (a_ok[i] && ts >= 0 && ts < p.S) ? ((a_row[i] + j) * p.ldx + a_col[i]) * 4 : OOR;
+      const int va = (a_t[i] >= 0 && ts >= 0 && ts < p.S) ? ((a_row[i] + j) * p.ldx + a_col[i]) * 4 : OOR;
+      if (A_EVEN || ea(i) < TOTA)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)&As[ea(i) * RPI * BK], 16, va, soA, 0, 0);
     }
-  };
-  auto dma_chunk = [&](float* As, float* Bs, int cc, int ch) {
-    const int soA = cc * BK * 4, soB = ch * BK * 4;
 #pragma unroll
-    for (int i = 0; i < IA; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)&As[(wid * IA + i) * RPI * BK], 16, va[i], soA, 0, 0);
-#pragma unroll
-    for (int i = 0; i < IB; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)&Bs[(wid * IB + i) * RPI * BK], 16, vb[i], soB, 0, 0);
+    for (int i = 0; i < IB; ++i) {
+      if (B_EVEN || eb(i) < TOTB)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)&Bs[eb(i) * RPI * BK], 16, vb[i], soB, 0, 0);
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -147,43 +158,73 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemm p, int ntn) {
 #pragma unroll
   for (int g = 0; g < BK / 8; ++g) foff[g] = frow * BK + (((2 * g + fh) ^ ((frow >> FSH) & FMSK)) * 4);
 
-  int j = 0, cc = 0;
-  set_tap(0);
-  dma_chunk(As0, Bs0, 0, 0);
+  // this group's slices of the four staging objects
+  float* const A0 = As0 + grp * BM * BK;
+  float* const A1 = As1 + grp * BM * BK;
+  float* const B0 = Bs0 + grp * BN * BK;
+  float* const B1 = Bs1 + grp * BN * BK;
+
+  // group g owns chunks g, g + KS, g + 2 KS, ...; all groups run the same number of steps (barriers are block-wide)
+  const int nsteps = (nch + KS - 1) / KS;
+  if (grp < nch) dma_chunk(A0, B0, grp);
   __syncthreads();
 
-  // one K-chunk: prefetch chunk ch+1 into the OTHER buffer pair, then 4*TM*TN*(BK/8) MFMAs on this one
-  auto step = [&](int ch, const float* Ac, const float* Bc, float* An, float* Bn) {
-    if (ch + 1 < nch) {
-      if (++cc == cpj) {
-        cc = 0;
-        ++j;
-        set_tap(j);
+  // one step: prefetch this group's next chunk into the OTHER buffer pair, then 4*TM*TN*(BK/8) MFMAs on this one
+  auto step = [&](int st, const float* Ac, const float* Bc, float* An, float* Bn) {
+    const int ch = st * KS + grp;
+    if (ch + KS < nch) dma_chunk(An, Bn, ch + KS);
+    if (KS == 1 || ch < nch) {
+      const float* as = Ac + wm0 * BK;
+      const float* bs = Bc + wn0 * BK;
+#pragma unroll
+      for (int g = 0; g < BK / 8; ++g) {
+        f32x4 a[TM], b[TN];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * BK + foff[g]);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * BK + foff[g]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], acc[mi][ni], 0, 0, 0);
       }
-      dma_chunk(An, Bn, cc, ch + 1);
     }
-    const float* as = Ac + wm0 * BK;
-    const float* bs = Bc + wn0 * BK;
-#pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      f32x4 a[TM], b[TN];
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * BK + foff[g]);
-#pragma unroll
-      for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * BK + foff[g]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < TN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], acc[mi][ni], 0, 0, 0);
-    }
-    __syncthreads();  // drains this chunk's DMA (vmcnt) and fences the buffer swap
+    __syncthreads();  // drains this step's DMA (vmcnt) and fences the buffer swap
   };
-  for (int ch = 0; ch < nch; ch += 2) {
-    step(ch, As0, Bs0, As1, Bs1);
-    if (ch + 1 < nch) step(ch + 1, As1, Bs1, As0, Bs0);
+  for (int st = 0; st < nsteps; st += 2) {
+    step(st, A0, B0, A1, B1);
+    if (st + 1 < nsteps) step(st + 1, A1, B1, A0, B0);
+  }
+
+  if (KS > 1) {
+    // sum the K-split partial tiles: groups 1..KS-1 park their accumulators in the (now idle) A staging buffers,
+    // lane-linear, group 0 adds them in group order and runs the epilogue
+    constexpr int TILE = BM * BN;
+    constexpr int PER_OBJ = (KS * BM * BK) / TILE > 0 ? (KS * BM * BK) / TILE : 1;
+    if (grp > 0) {
+      float* red = ((grp - 1) / PER_OBJ ? As1 : As0) + ((grp - 1) % PER_OBJ) * TILE;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[(((wid * TM + mi) * TN + ni) * 16 + r) * 64 + lane] = acc[mi][ni][r];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g2 = 1; g2 < KS; ++g2) {
+      const float* red = ((g2 - 1) / PER_OBJ ? As1 : As0) + ((g2 - 1) % PER_OBJ) * TILE;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mi][ni][r] += red[(((wid * TM + mi) * TN + ni) * 16 + r) * 64 + lane];
+    }
   }
 
   // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -210,10 +251,10 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemm p, int ntn) {
 #endif
 }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int KS = 1, int WGM = 2, int WGN = 2>
 static hipError_t launch_t(const ConvGemm& p, hipStream_t st) {
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((k_conv_gemm<BM, BN, BK>), dim3(ntm * ntn), dim3(256), 0, st, p, ntn);
+  hipLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, p, ntn);
   return hipGetLastError();
 }
 
@@ -223,12 +264,22 @@ hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) {
   // descriptor offsets are 31-bit: a tile's rows (BM + KW) * ldx and BN * K floats must stay below 2^29 floats
   if ((long long)(128 + p.KW) * p.ldx >= (1ll << 29) || (long long)128 * p.KW * p.Cin >= (1ll << 29)) return hipErrorInvalidValue;
   const bool bk32 = (p.Cin % 32) == 0;
-  // Tile choice (tools/lab/gemm_lab.hip sweep on the path's shapes, MI355X): the kernel is fastest with MANY small
-  // independent workgroups per CU (their barrier/DMA phases interleave and keep the matrix pipe fed), so the
-  // 64-row tile wins over 128x128 everywhere; 64x128 halves the B-operand traffic when N and the grid allow it.
-  const long tiles_wide = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
-  const bool wide = p.N >= 128 && tiles_wide >= 1024;
-  if (wide) return bk32 ? launch_t<64, 128, 32>(p, st) : launch_t<64, 128, 16>(p, st);
+  // Tile / wave-grid choice (tools/lab sweeps on the path's shapes, MI355X, same-run comparisons).  What wins is
+  // many waves per workgroup with ONE 32x32 MFMA tile each: 8 waves as 2x4 over a 64x256 or 64x128 block tile.  The
+  // DMA issue cost of a chunk is spread over 8 waves, each barrier interval still holds 16-32 MFMAs per wave, and
+  // 2+ workgroups per CU interleave their barrier phases.  (4-wave 2x2 grids with 2x2 tiles per wave: 110-125
+  // TFLOP/s on the dominant shape; 2x4 grids: 139-141.)
+  const long rows64 = (p.M + 63) / 64;
+  if (bk32 && p.N >= 512 && rows64 * ((p.N + 255) / 256) >= 512) return launch_t<64, 256, 32, 1, 2, 4>(p, st);
+  if (bk32 && p.N >= 128 && rows64 * ((p.N + 127) / 128) >= 192) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
+  // Few output tiles (encoder-side GEMMs, single-utterance latency): the chip is not full and each tile's serial
+  // K loop sets the launch time, so split K inside the workgroup (4 or 2 groups of 4 waves).
+  const long tiles = rows64 * ((p.N + 63) / 64);
+  const int nch = p.KW * (p.Cin / 32);
+  if (bk32 && nch >= 8) {
+    if (tiles <= 160) return launch_t<64, 64, 32, 4>(p, st);
+    if (tiles <= 384) return launch_t<64, 64, 32, 2>(p, st);
+  }
   return bk32 ? launch_t<64, 64, 32>(p, st) : launch_t<64, 64, 16>(p, st);
 }
 

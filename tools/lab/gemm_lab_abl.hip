@@ -5,18 +5,18 @@
 #include <cstdlib>
 #include <vector>
 #define NS_LAB 1
-#include "gemm_conv.hip"
+#include "gemm_var.hip"
 
 using namespace ns;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
-template <int BM, int BN, int BK, int KS = 1>
+template <int BM, int BN, int BK, int ABL = 0>
 float time_variant(ConvGemm p, int iters) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  for (int i = 0; i < 3; ++i) CK((launch_t<BM, BN, BK, KS>(p, 0)));
+  for (int i = 0; i < 3; ++i) CK((launch_t<BM, BN, BK, 1, ABL>(p, 0)));
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(a, 0));
-  for (int i = 0; i < iters; ++i) CK((launch_t<BM, BN, BK, KS>(p, 0)));
+  for (int i = 0; i < iters; ++i) CK((launch_t<BM, BN, BK, 1, ABL>(p, 0)));
   CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
   float ms; CK(hipEventElapsedTime(&ms, a, b));
   return ms / iters;
@@ -24,11 +24,12 @@ float time_variant(ConvGemm p, int iters) {
 
 int main(int argc, char** argv) {
   struct Shape { const char* name; int M, S, Cin, KW, N; } shapes[] = {
-    {"enc w2     M2048 k1 1024->256 ", 2048, 128, 1024, 1, 256},
-    {"enc fc     M2048 k1 256->256  ", 2048, 128, 256, 1, 256},
-    {"B1 conv9   M788  k9 256->1024 ", 788, 788, 256, 9, 1024},
-    {"B1 w2      M788  k1 1024->256 ", 788, 788, 1024, 1, 256},
-    {"B1 postnet M788  k5 512->512  ", 788, 788, 512, 5, 512},
+    {"ffn_w1 dec  (k9 256->1024)", 16160, 1010, 256, 9, 1024},
+    {"postnet mid (k5 512->512) ", 16160, 1010, 512, 5, 512},
+    {"ffn_w2 dec  (k1 1024->256)", 16160, 1010, 1024, 1, 256},
+    {"qkv dec     (k1 256->768) ", 16160, 1010, 256, 1, 768},
+    {"pred conv   (k3 256->256) ", 16160, 1010, 256, 3, 256},
+    {"ffn_w1 enc  (k9 256->1024)", 2048, 128, 256, 9, 1024},
   };
   for (auto& s : shapes) {
     size_t nx = (size_t)s.M * s.Cin, nw = (size_t)s.N * s.KW * s.Cin, ny = (size_t)s.M * s.N;
@@ -45,9 +46,8 @@ int main(int argc, char** argv) {
     double gf = 2.0 * s.M * s.Cin * s.KW * s.N / 1e9;
     printf("%s  %.1f GFLOP\n", s.name, gf);
 #define RUN(BM, BN, BK) { float ms = time_variant<BM, BN, BK>(p, 10); printf("   %3dx%3dx%2d  %8.1f us  %6.1f TF/s\n", BM, BN, BK, ms * 1e3, gf / ms); }
-    RUN(64, 64, 32)
-#define RUNK(KS) { float ms = time_variant<64, 64, 32, KS>(p, 10); printf("    64x 64x32 KS=%d %8.1f us  %6.1f TF/s\n", KS, ms * 1e3, gf / ms); }
-    RUNK(2) RUNK(4)
+#define RUNA(BM, BN, BK, A) { float ms = time_variant<BM, BN, BK, A>(p, 10); printf("   %3dx%3dx%2d abl=%d %8.1f us  %6.1f TF/s\n", BM, BN, BK, A, ms * 1e3, gf / ms); }
+    RUNA(64, 128, 32, 0) RUNA(64, 128, 32, 1) RUNA(64, 128, 32, 3) RUNA(64, 64, 32, 0) RUNA(64, 64, 32, 1) RUNA(64, 64, 32, 3) RUNA(128, 128, 32, 0) RUNA(128, 128, 32, 1) RUNA(128, 128, 32, 3)
 #ifdef NS_LAB_EXTRA
     NS_LAB_EXTRA
 #endif

@@ -5,7 +5,7 @@
 #include <cstdlib>
 #include <vector>
 #define NS_LAB 1
-#include "gemm_conv.hip"
+#include "gemm_var3.hip"
 
 using namespace ns;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -48,6 +48,12 @@ int main(int argc, char** argv) {
     RUN(64, 64, 32)
 #define RUNK(KS) { float ms = time_variant<64, 64, 32, KS>(p, 10); printf("    64x 64x32 KS=%d %8.1f us  %6.1f TF/s\n", KS, ms * 1e3, gf / ms); }
     RUNK(2) RUNK(4)
+    { for (int i = 0; i < 3; ++i) CK((launch_t3<64, 64, 32>(p, 0))); hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); CK(hipDeviceSynchronize()); CK(hipEventRecord(a, 0));
+      for (int i = 0; i < 10; ++i) CK((launch_t3<64, 64, 32>(p, 0))); CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 10;
+      printf("    64x 64x32 3-stage %8.1f us  %6.1f TF/s\n", ms * 1e3, gf / ms);
+      // correctness vs the 2-stage kernel
+      std::vector<float> r0(ny), r1(ny); CK((launch_t<64, 64, 32>(p, 0))); CK(hipMemcpy(r0.data(), dy, ny * 4, hipMemcpyDeviceToHost)); CK(hipMemset(dy, 0, ny * 4));
+      CK((launch_t3<64, 64, 32>(p, 0))); CK(hipMemcpy(r1.data(), dy, ny * 4, hipMemcpyDeviceToHost)); double md = 0; for (size_t i = 0; i < ny; ++i) md = fmax(md, fabs(r0[i] - r1[i])); printf("    max |2-stage - 3-stage| = %g\n", md); }
 #ifdef NS_LAB_EXTRA
     NS_LAB_EXTRA
 #endif

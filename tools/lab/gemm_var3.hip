@@ -1,49 +1,9 @@
-// Conv1D-as-GEMM / Linear on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
-//
-// Every dense contraction of the path except attention goes through this kernel:
-//   Linear (KW=1): QKV / fc projections (transformer/SubLayers.py:18-25), mel_linear
-//   Conv1d k=9 / k=1 of the FFT block's feed-forward (transformer/SubLayers.py:70-82)
-//   Conv1d k=3 of the variance predictors (model/modules.py:245-276)
-//   Conv1d k=5 of the PostNet with eval-BatchNorm folded in (transformer/Layers.py:107-167)
-//
-// The convolution is an implicit GEMM: activations stay [B*S, Cin] row-major in HBM and tap j of the
-// kernel window is just the same matrix shifted by (j - pad) rows, zero outside the utterance's [0,S)
-// window.  K runs tap-major (k = j*Cin + c), BK divides Cin, so one K-chunk touches one tap.
-//
-// Tiling (wave64): block tile BMxBN computed by 4 waves as 2x2, wave tile (BM/2)x(BN/2) as a grid of 32x32 MFMA
-// tiles, K-chunk BK double-buffered in LDS.  KS > 1 adds an in-workgroup split of K: KS groups of 4 waves each take
-// every KS-th chunk into their own accumulators and the partial tiles are summed through LDS at the end.  It is
-// used when the output has too few tiles to occupy the chip (the encoder's [B*L, *] GEMMs, single-utterance
-// latency): the serial K loop of a tile, not the matrix pipe, bounds those launches.
-//
-// Staging is LDS-DMA (`buffer_load_dwordx4 ... lds`): operands go HBM/L2 -> LDS without touching VGPRs, the
-// zero padding of the convolution and the M/N tile tails come for free from the buffer descriptor's
-// out-of-range rule (a lane whose voffset is the OOR marker writes zeros to LDS), and the per-chunk cost on the
-// issuing wave is a handful of DMA instructions with a scalar offset bump — no address VALU, no ds_write pass.
-// (Measured on the dominant shape: register-staged version 106 TFLOP/s, its compute-only ablation 137; see tools/lab.)
-//
-// The DMA destination is lane-linear (wave-uniform base + lane*16 B), so rows cannot be padded; bank conflicts
-// of the fragment reads are removed by an XOR swizzle applied on the SOURCE side: 16-byte slot s of tile row r
-// holds column chunk c = s ^ f(r), f(r) = (r>>1)&7 for 128-B rows (BK=32), (r>>2)&3 for 64-B rows (BK=16);
-// the reads apply the same XOR.  With it every ds_read_b128 lane group touches 16 distinct 16-B bank slots
-// (SQ_LDS_BANK_CONFLICT = 0 in profiles/r01_pmc.md).
-//
-// Operand reads use the freedom to permute k identically on both operands: lane-half h of MFMA step e in
-// group g consumes k = 8g + 4h + e, so each lane reads its 4 steps' operands with ONE ds_read_b128.
-#include "kernels.h"
-
+#include "gemm_conv.hip"
 namespace ns {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-constexpr int OOR = (int)0x80000000;  // voffset marker: beyond num_records -> the DMA writes zeros
-
-template <int BM, int BN, int BK, int KS, int ABL = 0>
-__global__ __launch_bounds__(256 * KS) void k_conv_gemm(ConvGemm p, int ntn) {
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void k_conv_gemm3(ConvGemm p, int ntn) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type does not exist in the host pass; it only needs the stub
-  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int KS = 1; constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int CPR = BK / 4;         // 16-B chunks per tile row
   constexpr int RPI = 64 / CPR;       // tile rows one wave-wide DMA instruction fills
@@ -53,7 +13,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv_gemm(ConvGemm p, int ntn) {
   constexpr int FMSK = CPR - 1;
   static_assert(BK == 64 || BK == 32 || BK == 16, "BK");
   static_assert(IA >= 1 && IB >= 1, "tile too small for 4 waves");
-  static_assert(KS == 1 || (KS - 1) * BM * BN <= 2 * KS * BM * BK, "split-K partial tiles must fit the A staging buffers");
+  static_assert(true, "split-K partial tiles must fit the A staging buffers");
 
   // Four DISTINCT LDS objects (not [2][...] arrays) and a 2x unrolled K loop with a static buffer index: hipcc tracks
   // in-flight LDS-DMA per LDS object, so a ds_read from As0 does not wait for a DMA that is filling As1.  With one
@@ -63,6 +23,8 @@ __global__ __launch_bounds__(256 * KS) void k_conv_gemm(ConvGemm p, int ntn) {
   __shared__ __attribute__((aligned(16))) float As1[KS * BM * BK];
   __shared__ __attribute__((aligned(16))) float Bs0[KS * BN * BK];
   __shared__ __attribute__((aligned(16))) float Bs1[KS * BN * BK];
+  __shared__ __attribute__((aligned(16))) float As2[BM * BK];
+  __shared__ __attribute__((aligned(16))) float Bs2[BN * BK];
 
   // XCD-aware bijective remap.  Workgroup b runs on XCD b%8 (observed, used for speed only).  Tiles are ordered
   // "super-row by super-row": the M-tiles are split into 8 contiguous groups, and inside a group the order is
@@ -156,38 +118,40 @@ __global__ __launch_bounds__(256 * KS) void k_conv_gemm(ConvGemm p, int ntn) {
   float* const B1 = Bs1 + grp * BN * BK;
 
   // group g owns chunks g, g + KS, g + 2 KS, ...; all groups run the same number of steps (barriers are block-wide)
-  const int nsteps = (nch + KS - 1) / KS;
-  if (grp < nch) dma_chunk(A0, B0, grp);
-  __syncthreads();
-
-  // one step: prefetch this group's next chunk into the OTHER buffer pair, then 4*TM*TN*(BK/8) MFMAs on this one
-  auto step = [&](int st, const float* Ac, const float* Bc, float* An, float* Bn) {
-    const int ch = st * KS + grp;
-    if (!(ABL & 1)) { if (ch + KS < nch) dma_chunk(An, Bn, ch + KS); }
-    if (KS == 1 || ch < nch) {
-      const float* as = Ac + wm0 * BK;
-      const float* bs = Bc + wn0 * BK;
+  constexpr int IPC = IA + IB;  // DMA instructions per chunk per wave
+  dma_chunk(As0, Bs0, 0);
+  if (nch > 1) dma_chunk(As1, Bs1, 1);
+  if (nch > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPC) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  auto step = [&](int ch, const float* Ac, const float* Bc, float* An, float* Bn) {
+    // chunk ch is in (Ac,Bc) and landed; chunk ch+1 is in flight; issue chunk ch+2 into (An,Bn) (held chunk ch-1)
+    if (ch + 2 < nch) dma_chunk(An, Bn, ch + 2);
+    const float* as = Ac + wm0 * BK;
+    const float* bs = Bc + wn0 * BK;
 #pragma unroll
-      for (int g = 0; g < BK / 8; ++g) {
-        f32x4 a[TM], b[TN];
+    for (int g = 0; g < BK / 8; ++g) {
+      f32x4 a[TM], b[TN];
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * BK + foff[g]);
+      for (int mi = 0; mi < TM; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * BK + foff[g]);
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * BK + foff[g]);
+      for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * BK + foff[g]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int mi = 0; mi < TM; ++mi)
+        for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], acc[mi][ni], 0, 0, 0);
-      }
+          for (int ni = 0; ni < TN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], acc[mi][ni], 0, 0, 0);
     }
-    if (!(ABL & 2)) __syncthreads();
+    // chunk ch+1 must have landed (own DMAs) before anyone reads it; chunk ch+2 may stay in flight
+    if (ch + 2 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPC) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   };
-  for (int st = 0; st < nsteps; st += 2) {
-    step(st, A0, B0, A1, B1);
-    if (st + 1 < nsteps) step(st + 1, A1, B1, A0, B0);
+  for (int ch = 0; ch < nch; ch += 3) {
+    step(ch, As0, Bs0, As2, Bs2);
+    if (ch + 1 < nch) step(ch + 1, As1, Bs1, As0, Bs0);
+    if (ch + 2 < nch) step(ch + 2, As2, Bs2, As1, Bs1);
   }
 
   if (KS > 1) {
@@ -242,34 +206,11 @@ __global__ __launch_bounds__(256 * KS) void k_conv_gemm(ConvGemm p, int ntn) {
 #endif
 }
 
-template <int BM, int BN, int BK, int KS = 1, int ABL = 0>
-static hipError_t launch_t(const ConvGemm& p, hipStream_t st) {
+
+template <int BM, int BN, int BK>
+static hipError_t launch_t3(const ConvGemm& p, hipStream_t st) {
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, ABL>), dim3(ntm * ntn), dim3(256 * KS), 0, st, p, ntn);
+  hipLaunchKernelGGL((k_conv_gemm3<BM, BN, BK>), dim3(ntm * ntn), dim3(256), 0, st, p, ntn);
   return hipGetLastError();
 }
-
-hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) {
-  if (p.M <= 0 || p.N <= 0) return hipSuccess;
-  if (p.Cin % 16 != 0 || (p.ldx & 3) != 0) return hipErrorInvalidValue;
-  // descriptor offsets are 31-bit: a tile's rows (BM + KW) * ldx and BN * K floats must stay below 2^29 floats
-  if ((long long)(128 + p.KW) * p.ldx >= (1ll << 29) || (long long)128 * p.KW * p.Cin >= (1ll << 29)) return hipErrorInvalidValue;
-  const bool bk32 = (p.Cin % 32) == 0;
-  // Tile choice (tools/lab/gemm_lab.hip sweep on the path's shapes, MI355X): the kernel is fastest with MANY small
-  // independent workgroups per CU (their barrier/DMA phases interleave and keep the matrix pipe fed), so the
-  // 64-row tile wins over 128x128 everywhere; 64x128 halves the B-operand traffic when N and the grid allow it.
-  const long tiles_wide = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
-  const bool wide = p.N >= 128 && tiles_wide >= 1024;
-  if (wide) return bk32 ? launch_t<64, 128, 32>(p, st) : launch_t<64, 128, 16>(p, st);
-  // Few output tiles (encoder-side GEMMs, single-utterance latency): the chip is not full and each tile's serial
-  // K loop sets the launch time, so split K inside the workgroup (4 or 2 groups of 4 waves).
-  const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
-  const int nch = p.KW * (p.Cin / 32);
-  if (bk32 && nch >= 8) {
-    if (tiles <= 160) return launch_t<64, 64, 32, 4>(p, st);
-    if (tiles <= 384) return launch_t<64, 64, 32, 2>(p, st);
-  }
-  return bk32 ? launch_t<64, 64, 32>(p, st) : launch_t<64, 64, 16>(p, st);
 }
-
-}  // namespace ns
