@@ -270,7 +270,7 @@ hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) {
   // 2+ workgroups per CU interleave their barrier phases.  (4-wave 2x2 grids with 2x2 tiles per wave: 110-125
   // TFLOP/s on the dominant shape; 2x4 grids: 139-141.)
   const long rows64 = (p.M + 63) / 64;
-  if (bk32 && p.N >= 512 && rows64 * ((p.N + 255) / 256) >= 512) return launch_t<64, 256, 32, 1, 2, 4>(p, st);
+  if (bk32 && p.N >= 512 && rows64 * ((p.N + 255) / 256) >= 400) return launch_t<64, 256, 32, 1, 2, 4>(p, st);
   if (bk32 && p.N >= 128 && rows64 * ((p.N + 127) / 128) >= 192) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
   // Few output tiles (encoder-side GEMMs, single-utterance latency): the chip is not full and each tile's serial
   // K loop sets the launch time, so split K inside the workgroup (4 or 2 groups of 4 waves).
