@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Turn one round's rocprofv3 outputs (gpurun_out/rNN_{trace,fetch,write,mfma,lds}/t_results.db + rNN_bench*.json)
+into the committed summaries under profiles/:
+
+    python tools/make_profiles.py r01
+
+* profiles/rNN_kernel_stats.md          per-kernel stats of `rocprofv3 --kernel-trace --stats -- python bench.py ...`
+* profiles/rNN_pmc.md                   per-dispatch PMC averages (separate passes) for the hot kernels
+* profiles/dominant_kernel_traffic.json what bench.py reports as roofline.traffic (HBM bytes per launch)
+* profiles/rNN_bench.json               the bench line of the same build (un-profiled) and under the trace
+"""
+import json
+import re
+import subprocess
+import sys
+
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r01"
+G = "gpurun_out"
+
+
+def run(*a):
+    return subprocess.run(["python", *a], capture_output=True, text=True).stdout
+
+
+def pmc_rows(db):
+    rows = {}
+    for line in run("tools/rocpd_pmc.py", db).splitlines():
+        m = re.match(r"\| `(.+?)` \| (\d+) \| (\d+) \| ([\d.]+) \| (\w+) \| ([\d.]+) \|", line)
+        if m:
+            rows[(m.group(1), int(m.group(2)), m.group(5))] = (float(m.group(6)), float(m.group(4)), int(m.group(3)))
+    return rows
+
+
+open(f"profiles/{ROUND}_kernel_stats.md", "w").write(run("tools/rocpd_stats.py", f"{G}/{ROUND}_trace/t_results.db"))
+
+bench = json.load(open(f"{G}/{ROUND}_bench.json"))
+under = json.load(open(f"{G}/{ROUND}_bench_under_trace.json"))
+json.dump({"bench": bench, "bench_under_kernel_trace": under}, open(f"profiles/{ROUND}_bench.json", "w"), indent=1)
+
+# the dominant kernel = the most expensive (kernel, grid) of the trace
+f = pmc_rows(f"{G}/{ROUND}_fetch/t_results.db")
+w = pmc_rows(f"{G}/{ROUND}_write/t_results.db")
+m = pmc_rows(f"{G}/{ROUND}_mfma/t_results.db")
+dom = max((k for k in f if k[2] == "FETCH_SIZE" and "k_conv_gemm" in k[0]), key=lambda k: f[k][1] * f[k][2])
+kname, wgs = dom[0], dom[1]
+cfgw = bench["config"]["workload"]
+T_pad = int(re.search(r"T_pad (\d+)", cfgw).group(1))
+rows = bench["config"]["global_batch"] * T_pad
+alg = (rows * 256 + 1024 * 2304 + rows * 1024) * 4
+fetch_b = f[(kname, wgs, "FETCH_SIZE")][0] * 1024 * 2  # gfx950: FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md §HBM)
+write_b = w[(kname, wgs, "WRITE_SIZE")][0] * 1024
+busy = m[(kname, wgs, "SQ_VALU_MFMA_BUSY_CYCLES")][0]
+gui = m[(kname, wgs, "GRBM_GUI_ACTIVE")][0]
+dur = m[(kname, wgs, "GRBM_GUI_ACTIVE")][1]
+d = {
+    "kernel": f"{kname} (decoder FFN w_1: Conv1d k=9 256->1024, bias+ReLU), {wgs} workgroups, rows B*T_pad = {rows}",
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / MFMA counters, one pass each, `python bench.py --steps 5 --warmup 2`; per-launch averages",
+    "fetch_size_kb_raw": f[(kname, wgs, "FETCH_SIZE")][0], "write_size_kb_raw": w[(kname, wgs, "WRITE_SIZE")][0],
+    "fetch_bytes_corrected_x2": fetch_b, "write_bytes": write_b, "hbm_bytes_per_launch": fetch_b + write_b,
+    "algorithmic_bytes_per_launch": alg,
+    "note": "FETCH_SIZE counts the L2's fabric-side requests (Infinity-Cache hits included); the 9.4 MB weight matrix is fetched once per XCD (8x = 75 MB), the activation rows once",
+    "mfma_util_pct": round(100 * busy / ((gui / 8) * 1024), 2), "clock_ghz_under_pmc": round(gui / 8 / (dur * 1e-6) / 1e9, 3),
+    "mfma_flops_executed": m[(kname, wgs, "SQ_INSTS_VALU_MFMA_MOPS_F32")][0] * 512, "avg_duration_us_under_pmc": dur,
+}
+json.dump(d, open("profiles/dominant_kernel_traffic.json", "w"), indent=1)
+
+with open(f"profiles/{ROUND}_pmc.md", "w") as fh:
+    fh.write(f"# PMC passes for {ROUND} (rocprofv3 --pmc, one counter group per pass; per-dispatch averages, hot kernels only)\n")
+    for tag in ("fetch", "write", "mfma", "lds"):
+        out = run("tools/rocpd_pmc.py", f"{G}/{ROUND}_{tag}/t_results.db").splitlines()
+        keep = [l for l in out if l.startswith("| kernel") or l.startswith("|---")]
+        body = [l for l in out if l.startswith("| `")]
+        # hot kernels of the benchmark workload: large grids only
+        body = [l for l in body if int(l.split("|")[2]) >= 250]
+        fh.write(f"\n## pass: {tag}\n\n" + "\n".join(keep + body[:40]) + "\n")
+print(json.dumps(d, indent=1))
+print(bench["ms_per_step"], bench["value"], bench["roofline"])
