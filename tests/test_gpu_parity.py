@@ -432,3 +432,43 @@ def test_max_mel_len_global_pad_mode():
             assert torch.equal(padded[1][b, :lens[b]], base[1][b, :lens[b]])
     with pytest.raises(ValueError, match="smaller than the longest"):
         m(dev(z["speakers"]), dev(z["texts"]), dev(z["in_src_lens"]), int(meta["L"]), max_mel_len=T - 1)
+
+
+def test_random_shapes_vs_oracle():
+    """Fuzz over batch shapes (tile tails of every GEMM variant, ragged lengths, tiny and >128-row utterances,
+    1..3 frames per phoneme): HIP path vs the oracle on the same seeded inputs, discrete decisions pinned with targets."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from oracle import fs2_oracle as orc
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    rs = np.random.RandomState(2024)
+    cfg = wl.model_config("tiny")
+    checked = 0
+    for fpp in (1.0, 3.0):
+        sd = wl.synth_state_dict(cfg, seed=1, frames_per_phoneme=fpp)
+        w = orc.to_torch_weights(sd)
+        m = FastSpeech2Align(wl.preprocess_config(), cfg).to("cuda").eval()
+        m.load_state_dict(sd)
+        for _ in range(6):
+            B = int(rs.randint(1, 7))
+            L = int(rs.choice([1, 2, 5, 31, 32, 33, 63, 64, 65, 100, 129, 200]))
+            lens = np.maximum(1, rs.randint(1, L + 1, size=B))
+            lens[rs.randint(B)] = L
+            inp = wl.synth_inputs(B, L, seed=int(rs.randint(1 << 20)), src_lens=lens)
+            with torch.no_grad():
+                ref = orc.forward(w, cfg, torch.from_numpy(inp[0]), torch.from_numpy(inp[1]), torch.from_numpy(inp[2]), inp[3])
+                out = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3])
+            close(out[4], ref[4].numpy(), 1e-4, f"log durations B={B} L={L}")
+            half = np.abs((np.exp(ref[4].numpy().astype(np.float64)) - 1.0) % 1.0 - 0.5)
+            flips = out[5].cpu().numpy() != ref[5].numpy()
+            assert np.all(half[flips] < 5e-5), (B, L, lens.tolist())
+            if flips.any() or int(ref[9].max()) == 0:
+                continue
+            assert np.array_equal(out[9].cpu().numpy(), ref[9].numpy())
+            with torch.no_grad():
+                tf = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3], p_targets=ref[2].cuda(), e_targets=ref[3].cuda())
+            close(tf[3], ref[3].numpy(), MEL_TOL, f"energy B={B} L={L}")
+            close(tf[0], ref[0].numpy(), MEL_TOL, f"mel B={B} L={L} lens={lens.tolist()}")
+            close(tf[1], ref[1].numpy(), MEL_TOL, f"postnet mel B={B} L={L}")
+            checked += 1
+    assert checked >= 8
