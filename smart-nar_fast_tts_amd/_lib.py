@@ -57,7 +57,7 @@ SIGNATURES = {
     "ns_op_mel_linear": (_I, [_P, _P, _I, _I, _P, _P]),
     "ns_op_postnet": (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
     "ns_op_ffn_conv1": (_I, [_P, _S, _P, _I, _I, _P, _P]),
-    "ns_op_attention_core": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "ns_op_attention_core": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _Z, _P]),
     "ns_profile_enable": (_I, [_P, _I]),
     "ns_profile_read": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

@@ -377,7 +377,9 @@ static int mha(const ns_model* m, const LayerW& L, int d, int H, const float* x,
                float* out, bool mask_rows, Scratch& sc, hipStream_t st) {
   const int M = B * S;
   NS_TRY(gemm(x, d, m->P(L.qkv_w), m->P(L.qkv_b), nullptr, 0, sc.qkv, 3 * d, M, 3 * d, d, 1, S, ACT_NONE, st));
-  NS_HIP(launch_attention(sc.qkv, lens, B, S, H, d / H, sc.att, st));
+  // hid | vp1 | vp2 are carved back to back and idle during attention: scratch for its split-key partials (small grids)
+  NS_HIP(launch_attention(sc.qkv, lens, B, S, H, d / H, sc.att, sc.hid,
+                          (size_t)M * (imax(m->cfg.d_inner, 2 * (size_t)m->cfg.postnet_dim) + 2 * (size_t)m->cfg.vp_filter), st));
   NS_TRY(gemm(sc.att, d, m->P(L.fc_w), m->P(L.fc_b), x, d, sc.t1, d, M, d, d, 1, S, ACT_NONE, st));
   NS_HIP(launch_layernorm(sc.t1, m->P(L.ln1_g), m->P(L.ln1_b), out, M, d, S, mask_rows ? lens : nullptr, st));
   return 0;
@@ -736,8 +738,10 @@ extern "C" int ns_op_postnet(ns_model* m, const float* mel, int B, int T, float*
   NS_OP_PROLOGUE(B, T);
   return postnet(m, mel, B, T, nullptr, out, sc, st);
 }
-extern "C" int ns_op_attention_core(const float* qkv, const int64_t* lens, int B, int S, int H, int dk, float* out, void* stream) {
-  NS_HIP(launch_attention(qkv, (const long long*)lens, B, S, H, dk, out, (hipStream_t)stream));
+extern "C" int ns_op_attention_core(const float* qkv, const int64_t* lens, int B, int S, int H, int dk, float* out, void* scratch,
+                                    size_t scratch_bytes, void* stream) {
+  NS_HIP(launch_attention(qkv, (const long long*)lens, B, S, H, dk, out, (float*)scratch, scratch_bytes / sizeof(float),
+                          (hipStream_t)stream));
   return 0;
 }
 extern "C" int ns_op_ffn_conv1(ns_model* m, const char* prefix, const float* x, int B, int S, float* hidden, void* stream) {

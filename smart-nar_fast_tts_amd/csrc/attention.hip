@@ -34,7 +34,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int DK>
 __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, const long long* __restrict__ lens,
-                                                    int S, int d, float c_scale, float* __restrict__ out) {
+                                                    int S, int d, float c_scale, float* __restrict__ out, int nsplit,
+                                                    float* __restrict__ opart, float* __restrict__ mlpart) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BC = 32;                    // keys per tile
   constexpr int CPR = DK / 4;               // 16-B chunks per tile row
@@ -58,12 +59,18 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, qi = lane & 31;
-  const int q = blockIdx.x * 128 + wid * 32 + qi;
+  // nsplit > 1 (few workgroups, long key axis): workgroup (qt, sp) sweeps only the sp-th contiguous share of the key
+  // tiles and leaves an un-normalised partial (O^T, m, l) for k_attention_merge; softmax is exact per part
+  const int qt = blockIdx.x / nsplit, sp = blockIdx.x - qt * nsplit;
+  const int q = qt * 128 + wid * 32 + qi;
   const int ld = 3 * d;
   const float* base = qkv + (size_t)b * S * ld + hd * DK;
   long long len_ll = lens ? lens[b] : (long long)S;
   const int len = (int)(len_ll < S ? len_ll : S);
-  const int nkt = (len + BC - 1) / BC;
+  const int nkt_all = (len + BC - 1) / BC;
+  const int tps = (nkt_all + nsplit - 1) / nsplit;       // key tiles per split
+  const int t0 = sp * tps;                               // first key tile of this workgroup
+  const int nkt = max(0, min(nkt_all, t0 + tps) - t0);   // its number of key tiles (kt below is local: 0..nkt-1)
 
   // descriptors over this (batch, head)'s K and V column blocks; rows >= S are out of range -> the DMA writes zeros
   const int nrec = ((S - 1) * ld + DK) * 4;  // bytes from a head's column block in row 0 to its end in row S-1
@@ -84,12 +91,12 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   auto dma_k = [&](float* Kd, int kt) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)&Kd[(wid * NI + i) * RPI * DK], 16, vk[i] + kt * tile_step, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)&Kd[(wid * NI + i) * RPI * DK], 16, vk[i] + (t0 + kt) * tile_step, 0, 0, 0);
   };
   auto dma_v = [&](float* Vd, int kt) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)&Vd[(wid * NI + i) * RPI * DK], 16, vv[i] + kt * tile_step, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)&Vd[(wid * NI + i) * RPI * DK], 16, vv[i] + (t0 + kt) * tile_step, 0, 0, 0);
   };
 
   // Q^T operand: lane (q, h) keeps Q[q][8g + 4h + e], pre-multiplied by log2(e)/sqrt(d_k) so the scores come out
@@ -129,8 +136,8 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   };
   // key-padding mask + online softmax of tile kt; s becomes P, returns the O rescale factor
   auto softmax_tile = [&](int kt, f32x16& s) -> float {
-    if (kt * BC + BC > len) {  // wave-uniform: only the tile that straddles lens[b] needs the per-key compare
-      const int kbase = kt * BC + 4 * h;
+    if ((t0 + kt) * BC + BC > len) {  // wave-uniform: only the tile that straddles lens[b] needs the per-key compare
+      const int kbase = (t0 + kt) * BC + 4 * h;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kbase + (r & 3) + 8 * (r >> 2);
@@ -219,6 +226,22 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
+  if (opart) {  // split-key mode: un-normalised partial for the merge kernel
+    if (q < S) {
+      const size_t row = (size_t)sp * gridDim.z * S + (size_t)b * S + q;
+      float* dst = opart + row * d + hd * DK + 4 * h;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          *reinterpret_cast<f32x4*>(dst + 32 * db + 8 * u) = f32x4{o[db][4 * u], o[db][4 * u + 1], o[db][4 * u + 2], o[db][4 * u + 3]};
+      if (h == 0) {
+        mlpart[(row * gridDim.y + hd) * 2] = m_run;
+        mlpart[(row * gridDim.y + hd) * 2 + 1] = l_tot;
+      }
+    }
+    return;
+  }
   const float inv = 1.0f / l_tot;   // lens[b]==0 -> 0 * inf = NaN, as the reference
   if (q < S) {
     float* dst = out + ((size_t)b * S + q) * d + hd * DK + 4 * h;
@@ -233,16 +256,58 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
 #endif
 }
 
-hipError_t launch_attention(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, hipStream_t st) {
+// out[row, c] = sum_sp O_sp[row, c] 2^(m_sp - m) / sum_sp l_sp 2^(m_sp - m), m = max_sp m_sp (per row and head)
+__global__ __launch_bounds__(256) void k_attention_merge(const float* __restrict__ opart, const float* __restrict__ mlpart, int M,
+                                                          int d, int H, int dk, int nsplit, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  for (int c = lane * 4; c < d; c += 256) {
+    const int hd = c / dk;
+    float mx = -INFINITY;
+    for (int sp = 0; sp < nsplit; ++sp) mx = fmaxf(mx, mlpart[(((size_t)sp * M + m) * H + hd) * 2]);
+    const float m_use = (mx == -INFINITY) ? 0.f : mx;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float l = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+      const size_t row = (size_t)sp * M + m;
+      const float w = __builtin_amdgcn_exp2f(mlpart[(row * H + hd) * 2] - m_use);
+      l += mlpart[(row * H + hd) * 2 + 1] * w;
+      acc += *reinterpret_cast<const f32x4*>(opart + row * d + c) * w;
+    }
+    const float inv = 1.0f / l;  // no valid key at all -> 0 * inf = NaN, as the reference
+    *reinterpret_cast<f32x4*>(out + (size_t)m * d + c) = acc * inv;
+  }
+}
+
+hipError_t launch_attention(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, float* scratch,
+                            size_t scratch_floats, hipStream_t st) {
   if (B <= 0 || S <= 0) return hipSuccess;
   const int d = H * dk;
   if ((long long)S * 3 * d * 4 >= (1ll << 31)) return hipErrorInvalidValue;  // 31-bit descriptor offsets per utterance
   const float c = 1.4426950408889634f / sqrtf((float)dk);
-  dim3 grid((S + 127) / 128, H, B), block(256);
-  if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out);
-  else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out);
-  else if (dk == 32) hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out);
+  const int qtiles = (S + 127) / 128;
+  // Few workgroups and a long key axis (single-utterance latency): split the key sweep over up to 4 workgroups per
+  // query tile so more CUs take part, then merge the partials.  Needs nsplit * (M*d + 2*M*H) floats of scratch.
+  int nsplit = 1;
+  const long blocks = (long)qtiles * H * B;
+  const size_t M = (size_t)B * S;
+  if (scratch && blocks < 96 && S >= 256) {
+    nsplit = (int)(192 / blocks);
+    if (nsplit > 4) nsplit = 4;
+    if (nsplit > S / 128) nsplit = S / 128;
+    while (nsplit > 1 && (size_t)nsplit * (M * d + 2 * M * H) > scratch_floats) --nsplit;
+    if (nsplit < 1) nsplit = 1;
+  }
+  float* opart = nsplit > 1 ? scratch : nullptr;
+  float* mlpart = nsplit > 1 ? scratch + (size_t)nsplit * M * d : nullptr;
+  dim3 grid(qtiles * nsplit, H, B), block(256);
+  if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart);
+  else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart);
+  else if (dk == 32) hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart);
   else return hipErrorInvalidValue;
+  if (nsplit > 1)
+    hipLaunchKernelGGL(k_attention_merge, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, opart, mlpart, (int)M, d, H, dk, nsplit, out);
   return hipGetLastError();
 }
 

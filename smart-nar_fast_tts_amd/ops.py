@@ -194,14 +194,17 @@ def ffn_conv1(model, prefix, x, out=None):
     return out
 
 
-def attention_core(qkv, lens, n_head: int):
+def attention_core(qkv, lens, n_head: int, split_scratch: bool = True):
     """ScaledDotProductAttention on already-projected, head-packed q/k/v (transformer/Modules.py:14-25):
-    qkv [B,S,3*d] (Q | K | V, head h at h*dk inside each) -> merged heads [B,S,d]."""
+    qkv [B,S,3*d] (Q | K | V, head h at h*dk inside each) -> merged heads [B,S,d].  ``split_scratch`` hands the
+    kernel the scratch it needs to take its split-key path on small grids."""
     lib = _lib.load()
     B, S, d3 = qkv.shape
     d = d3 // 3
     qkv = qkv.contiguous()
     out = torch.empty(B, S, d, dtype=torch.float32, device=qkv.device)
     lens_p = _lib.ptr(lens.long().contiguous()) if lens is not None else _lib.ptr(None)
-    _lib.check(lib.ns_op_attention_core(_lib.ptr(qkv), lens_p, B, S, n_head, d // n_head, _lib.ptr(out), _st(qkv)), "attention_core")
+    scratch = torch.empty(4 * (B * S * d + 2 * B * S * n_head), dtype=torch.float32, device=qkv.device) if split_scratch else None
+    _lib.check(lib.ns_op_attention_core(_lib.ptr(qkv), lens_p, B, S, n_head, d // n_head, _lib.ptr(out), _lib.ptr(scratch),
+                                        0 if scratch is None else scratch.numel() * 4, _st(qkv)), "attention_core")
     return out

@@ -70,3 +70,26 @@ def test_attention_zero_length_gives_nan_like_reference():
     got = ops.attention_core(qkv.cuda(), torch.tensor([0, 40]).cuda(), 2).cpu()
     assert torch.isnan(got[0]).all()
     assert torch.isfinite(got[1]).all()
+
+
+@pytest.mark.parametrize("H,dk,S,lens", [(2, 128, 1000, [1000]), (2, 128, 700, [700, 130]), (8, 64, 513, [384]), (4, 32, 260, [260, 31, 0])])
+def test_attention_split_key_path(H, dk, S, lens):
+    """Few workgroups + long key axis (single-utterance latency) takes the split-key path (partials + merge kernel):
+    it must agree with float64 and, to rounding, with the single-sweep path on the same input — incl. splits that own
+    no valid key tile at all (short utterance beside a long one) and the all-masked NaN case."""
+    from smart_nar_fast_tts_amd import ops
+
+    torch.manual_seed(S + dk)
+    B = len(lens)
+    qkv = torch.randn(B, S, 3 * H * dk)
+    qkv[0, S // 2 + 7, H * dk:2 * H * dk] *= 4.0  # a dominant key in a late split: weights differ a lot between partials
+    lens_t = torch.tensor(lens)
+    split = ops.attention_core(qkv.cuda(), lens_t.cuda(), H, split_scratch=True).cpu()
+    single = ops.attention_core(qkv.cuda(), lens_t.cuda(), H, split_scratch=False).cpu()
+    ref = ref_attention(qkv, lens_t, H)
+    for b in range(B):
+        if lens[b] == 0:
+            assert torch.isnan(split[b]).all() and torch.isnan(single[b]).all()
+            continue
+        assert (split[b].double() - ref[b]).abs().max().item() < 2e-5
+        assert (split[b] - single[b]).abs().max().item() < 1e-5
