@@ -269,18 +269,26 @@ hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) {
   // DMA issue cost of a chunk is spread over 8 waves, each barrier interval still holds 16-32 MFMAs per wave, and
   // 2+ workgroups per CU interleave their barrier phases.  (4-wave 2x2 grids with 2x2 tiles per wave: 110-125
   // TFLOP/s on the dominant shape; 2x4 grids: 139-141.)
-  const long rows64 = (p.M + 63) / 64;
-  if (bk32 && p.N >= 512 && rows64 * ((p.N + 255) / 256) >= 400) return launch_t<64, 256, 32, 1, 2, 4>(p, st);
-  if (bk32 && p.N >= 128 && rows64 * ((p.N + 127) / 128) >= 192) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
-  // Few output tiles (encoder-side GEMMs, single-utterance latency): the chip is not full and each tile's serial
-  // K loop sets the launch time, so split K inside the workgroup (4 or 2 groups of 4 waves).
-  const long tiles = rows64 * ((p.N + 63) / 64);
-  const int nch = p.KW * (p.Cin / 32);
-  if (bk32 && nch >= 8) {
-    if (tiles <= 160) return launch_t<64, 64, 32, 4>(p, st);
-    if (tiles <= 384) return launch_t<64, 64, 32, 2>(p, st);
+  const long rows64 = (p.M + 63) / 64, rows32 = (p.M + 31) / 32;
+  auto wgs = [&](long rows, int bn) { return rows * ((p.N + bn - 1) / bn); };
+  if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400) return launch_t<64, 256, 32, 1, 2, 4>(p, st);
+  if (bk32 && p.N >= 128 && wgs(rows64, 128) > 256) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
+  // Fewer output tiles than that (encoder-side GEMMs, single-utterance latency): a workgroup's time is set by how fast
+  // ONE CU can pull its operand panels, (BM + BN) * K * 4 bytes, through LDS-DMA, so what matters is to put every CU to
+  // work — the smallest tile that still yields <= 256 workgroups (one round, one per CU) — and to spend the rest of the
+  // CU's wave slots and LDS on an in-workgroup split of K (KS groups, each with its own double buffer: KS x the bytes
+  // in flight).  Ladder measured on the path's shapes in tools/lab/gemm_lab_small.hip (same-run comparisons):
+  //   e.g. M=100 k9 256->1024: 64x64 KS4 44.7 us -> 32x32 KS8 19.3;  M=788 k1 1024->256: 23.9 -> 11.9;
+  //        M=788 k5 512->512: 51.2 -> 31.8 (32x64 KS4);  M=788 k9 256->1024: 49.5 -> 45.4 (32x128 KS2).
+  if (bk32) {
+    const int nch = p.KW * (p.Cin / 32);
+    if (wgs(rows32, 32) <= 256) return nch >= 16 ? launch_t<32, 32, 32, 8, 1, 1>(p, st) : launch_t<32, 32, 32, 4, 1, 1>(p, st);
+    if (wgs(rows32, 64) <= 256) return launch_t<32, 64, 32, 4, 1, 2>(p, st);
+    if (wgs(rows32, 128) <= 512) return launch_t<32, 128, 32, 2, 1, 4>(p, st);
+    return launch_t<64, 64, 32>(p, st);
   }
-  return bk32 ? launch_t<64, 64, 32>(p, st) : launch_t<64, 64, 16>(p, st);
+  if (wgs(rows32, 32) <= 512) return launch_t<32, 32, 16, 4, 1, 1>(p, st);
+  return launch_t<64, 64, 16>(p, st);
 }
 
 }  // namespace ns
