@@ -137,8 +137,8 @@ int ns_op_ffn_conv1(ns_model* m, const char* prefix, const float* x, int B, int 
 /* a5 alone (transformer/Modules.py:14-25 on already projected heads): qkv [B*S, 3*H*dk] with columns [0,d) = Q,
  * [d,2d) = K, [2d,3d) = V (head h at h*dk inside each), out [B*S, H*dk] = merged heads of
  * softmax(Q K^T / sqrt(dk) + (-inf at keys >= lens[b])) V.  dk in {32, 64, 128}. */
-/* scratch (nullable): device memory for the split-key path the kernel takes when a launch has few workgroups and a long
- * key axis (single-utterance latency); 4 * (B*S*H*dk + 2*B*S*H) floats always suffice. */
+/* scratch (nullable): device memory for the split-key path the kernel takes when a launch has few workgroups
+ * (single-utterance latency); 8 * (B*S*H*dk + 2*B*S*H) floats always suffice. */
 int ns_op_attention_core(const float* qkv, const int64_t* lens, int B, int S, int H, int dk, float* out, void* scratch,
                          size_t scratch_bytes, void* stream);
 

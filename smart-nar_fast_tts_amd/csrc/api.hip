@@ -319,7 +319,8 @@ struct Bump {
 };
 
 struct Scratch {  // per-stack temporaries for M rows
-  float *xa, *xb, *qkv, *att, *t1, *x1, *hid, *vp1, *vp2, *pos_ext;
+  float *xa, *xb, *qkv, *att, *t1, *x1, *hid, *vp1, *vp2, *pos_ext, *att_part;
+  size_t att_part_floats;
 };
 
 static size_t imax(size_t a, size_t b) { return a > b ? a : b; }
@@ -332,6 +333,12 @@ static Scratch carve(const ns_config& c, Bump& bp, size_t M, int S) {
   s.hid = bp.f(M * imax(c.d_inner, 2 * (size_t)c.postnet_dim));
   s.vp1 = bp.f(M * c.vp_filter); s.vp2 = bp.f(M * c.vp_filter);
   s.pos_ext = S > c.max_seq_len ? bp.f((size_t)S * d) : nullptr;
+  // attention's split-key partials: only launches with few workgroups take that path (kernels.h)
+  const int hmin = c.n_enc_head < c.n_dec_head ? c.n_enc_head : c.n_dec_head;
+  const int hmax = c.n_enc_head > c.n_dec_head ? c.n_enc_head : c.n_dec_head;
+  const size_t qtiles = ((size_t)S + 127) / 128;
+  s.att_part_floats = (M / (size_t)S) * qtiles * hmin < ATT_SPLIT_MAX_BLOCKS ? ATT_SPLIT_MAX * (M * d + 2 * M * hmax) : 0;
+  s.att_part = s.att_part_floats ? bp.f(s.att_part_floats) : nullptr;
   return s;
 }
 }  // namespace
@@ -377,9 +384,7 @@ static int mha(const ns_model* m, const LayerW& L, int d, int H, const float* x,
                float* out, bool mask_rows, Scratch& sc, hipStream_t st) {
   const int M = B * S;
   NS_TRY(gemm(x, d, m->P(L.qkv_w), m->P(L.qkv_b), nullptr, 0, sc.qkv, 3 * d, M, 3 * d, d, 1, S, ACT_NONE, st));
-  // hid | vp1 | vp2 are carved back to back and idle during attention: scratch for its split-key partials (small grids)
-  NS_HIP(launch_attention(sc.qkv, lens, B, S, H, d / H, sc.att, sc.hid,
-                          (size_t)M * (imax(m->cfg.d_inner, 2 * (size_t)m->cfg.postnet_dim) + 2 * (size_t)m->cfg.vp_filter), st));
+  NS_HIP(launch_attention(sc.qkv, lens, B, S, H, d / H, sc.att, sc.att_part, sc.att_part_floats, st));
   NS_TRY(gemm(sc.att, d, m->P(L.fc_w), m->P(L.fc_b), x, d, sc.t1, d, M, d, d, 1, S, ACT_NONE, st));
   NS_HIP(launch_layernorm(sc.t1, m->P(L.ln1_g), m->P(L.ln1_b), out, M, d, S, mask_rows ? lens : nullptr, st));
   return 0;

@@ -287,15 +287,16 @@ hipError_t launch_attention(const float* qkv, const long long* lens, int B, int 
   if ((long long)S * 3 * d * 4 >= (1ll << 31)) return hipErrorInvalidValue;  // 31-bit descriptor offsets per utterance
   const float c = 1.4426950408889634f / sqrtf((float)dk);
   const int qtiles = (S + 127) / 128;
-  // Few workgroups and a long key axis (single-utterance latency): split the key sweep over up to 4 workgroups per
-  // query tile so more CUs take part, then merge the partials.  Needs nsplit * (M*d + 2*M*H) floats of scratch.
+  // Few workgroups (single-utterance latency): a workgroup's time is its serial sweep over the key tiles, 128 fp32
+  // MFMAs per tile and wave, so split the sweep over up to ATT_SPLIT_MAX workgroups per query tile until the launch
+  // has ~256 of them, then merge the partials.  Needs nsplit * (M*d + 2*M*H) floats of scratch.
   int nsplit = 1;
   const long blocks = (long)qtiles * H * B;
   const size_t M = (size_t)B * S;
-  if (scratch && blocks < 96 && S >= 256) {
-    nsplit = (int)(192 / blocks);
-    if (nsplit > 4) nsplit = 4;
-    if (nsplit > S / 128) nsplit = S / 128;
+  if (scratch && blocks < ATT_SPLIT_MAX_BLOCKS) {
+    nsplit = (int)(256 / blocks);
+    if (nsplit > ATT_SPLIT_MAX) nsplit = ATT_SPLIT_MAX;
+    if (nsplit > (S + 31) / 32) nsplit = (S + 31) / 32;  // at least one 32-key tile each
     while (nsplit > 1 && (size_t)nsplit * (M * d + 2 * M * H) > scratch_floats) --nsplit;
     if (nsplit < 1) nsplit = 1;
   }

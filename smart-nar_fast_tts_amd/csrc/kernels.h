@@ -25,7 +25,9 @@ hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st);
 // Fused multi-head self attention over the packed projection buffer qkv [B*S, 3*d]
 // (cols [0,d) = Q, [d,2d) = K, [2d,3d) = V, head h at offset h*dk inside each).
 // out [B*S, d] = merge_heads( softmax(Q K^T / sqrt(dk) + (-inf at keys >= lens[b])) V )
-// scratch (optional, scratch_floats floats): enables the split-key path for launches with few workgroups
+// scratch (optional, scratch_floats floats): enables the split-key path, taken by launches of fewer than
+// ATT_SPLIT_MAX_BLOCKS workgroups: up to ATT_SPLIT_MAX key ranges, each needing B*S*(H*dk + 2*H) floats
+constexpr int ATT_SPLIT_MAX = 8, ATT_SPLIT_MAX_BLOCKS = 128;
 hipError_t launch_attention(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, float* scratch,
                             size_t scratch_floats, hipStream_t st);
 

@@ -204,7 +204,7 @@ def attention_core(qkv, lens, n_head: int, split_scratch: bool = True):
     qkv = qkv.contiguous()
     out = torch.empty(B, S, d, dtype=torch.float32, device=qkv.device)
     lens_p = _lib.ptr(lens.long().contiguous()) if lens is not None else _lib.ptr(None)
-    scratch = torch.empty(4 * (B * S * d + 2 * B * S * n_head), dtype=torch.float32, device=qkv.device) if split_scratch else None
+    scratch = torch.empty(8 * (B * S * d + 2 * B * S * n_head), dtype=torch.float32, device=qkv.device) if split_scratch else None
     _lib.check(lib.ns_op_attention_core(_lib.ptr(qkv), lens_p, B, S, n_head, d // n_head, _lib.ptr(out), _lib.ptr(scratch),
                                         0 if scratch is None else scratch.numel() * 4, _st(qkv)), "attention_core")
     return out
