@@ -8,7 +8,7 @@
 //
 // The convolution is an implicit GEMM: activations stay [B*S, Cin] row-major in HBM and tap j of the
 // kernel window is just the same matrix shifted by (j - pad) rows, zero outside the utterance's [0,S)
-// window.  K runs tap-major (k = j*Cin + c), BK divides Cin, so one K-chunk touches one tap.
+// window.  K is indexed tap-major in memory (k = j*Cin + c), BK divides Cin, so one K-chunk touches one tap.
 //
 // Tiling (wave64): block tile BMxBN computed by WGM x WGN waves, wave tile (BM/WGM)x(BN/WGN) as a grid of 32x32 MFMA
 // tiles, K-chunk BK double-buffered in LDS.  KS > 1 adds an in-workgroup split of K: KS groups of waves each take
@@ -126,10 +126,13 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
     const int r = eb(i) * RPI + lr;
     vb[i] = (n0 + r < p.N) ? (r * Kt + (ls ^ ((r >> FSH) & FMSK)) * 4) * 4 : OOR;
   }
-  // stage chunk ch (tap j = ch / cpj, channel block cc = ch % cpj) of this group into (As, Bs)
+  // stage chunk ch of this group into (As, Bs).  The chunks run channel-block major, tap minor (cc = ch / KW, tap
+  // j = ch % KW): the KW taps of one channel block re-read the same activation lines shifted by one row each, so they
+  // are issued back to back and hit in L2.  (Tap-major order put Cin/BK chunks of the whole XCD's row group between two
+  // uses of a line — a reuse distance of 2-5 MB against a 4 MB L2: 2-4x the fabric traffic, profiles/r01_pmc.md.)
   auto dma_chunk = [&](float* As, float* Bs, int ch) {
-    const int j = ch / cpj, cc = ch - j * cpj;
-    const int soA = cc * BK * 4, soB = ch * BK * 4;
+    const int cc = ch / p.KW, j = ch - cc * p.KW;
+    const int soA = cc * BK * 4, soB = (j * p.Cin + cc * BK) * 4;
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
       const int ts = a_t[i] + j - p.pad;
