@@ -517,7 +517,6 @@ extern "C" int ns_forward_durations(ns_model* m, const int64_t* texts, const int
   float* dur_keep = bp.f((size_t)B * L);
   Scratch sc = carve(c, bp, (size_t)B * L, L);
   const long long* lens = (const long long*)src_lens;
-  NS_HIP(launch_mask_from_lengths(lens, B, L, src_mask, st));
   NS_TRY(encoder(m, (const long long*)texts, lens, B, L, enc_out, sc, st));
   NS_TRY(predictor(m, m->pred[0], enc_out, lens, B, L, 1.0f, nullptr, log_d, nullptr, nullptr, nullptr, nullptr, sc, st));
   // phoneme_level features are predicted on the encoder output, before the length regulator, pitch first, and
@@ -532,9 +531,9 @@ extern "C" int ns_forward_durations(ns_model* m, const int64_t* texts, const int
     NS_TRY(predictor(m, m->pred[2], enc_out, lens, B, L, e_control, e_targets, e_pred, m->P(m->energy_bins), m->P(m->energy_emb),
                      nullptr, enc_out, sc, st));
   }
-  NS_HIP(launch_duration_round(log_d, B * L, d_control, d_rounded, st));
-  NS_HIP(launch_duration_scan(d_rounded, B, L, cum, (long long*)mel_lens, st));
-  NS_HIP(hipMemcpyAsync(dur_keep, d_rounded, (size_t)B * L * sizeof(float), hipMemcpyDeviceToDevice, st));
+  // src mask (utils/tools.py:89-97), duration rounding (model/modules.py:132-135), repeat counts + prefix sums + mel_len
+  // (:209-223): one launch
+  NS_HIP(launch_duration_tail(log_d, lens, B, L, d_control, d_rounded, dur_keep, cum, (long long*)mel_lens, src_mask, st));
   return 0;
 }
 
@@ -557,14 +556,14 @@ extern "C" int ns_forward_mel(ns_model* m, int B, int L, int T, const int64_t* m
   const long long* lens = (const long long*)mel_lens;
   const int d = c.d_dec, M = B * T;
 
-  NS_HIP(launch_mask_from_lengths(lens, B, T, mel_mask, st));
   if (c.length_regulator == 1) {
+    NS_HIP(launch_mask_from_lengths(lens, B, T, mel_mask, st));
     // extension: GaussianUpsampling (model/modules.py:166-192) in the LengthRegulator's place;
     // mel_len = sum of the rounded durations, frames past an utterance's own length are zero like pad()'s
     if ((size_t)B * (L + 1) > (size_t)M * c.vp_filter) return fail("ns_forward_mel: workspace too small for the Gaussian centres");
     NS_HIP(launch_gaussian_upsampling(enc_out, dur_keep, B, L, c.d_enc, T, T, sc.xa, sc.vp2, nullptr, lens, st));
   } else {
-    NS_HIP(launch_length_regulate(enc_out, cum, B, L, c.d_enc, T, sc.xa, st));
+    NS_HIP(launch_length_regulate(enc_out, cum, B, L, c.d_enc, T, sc.xa, mel_mask, st));  // + the mel mask
   }
   const float* pos;
   NS_TRY(position_rows(m, m->dec_pos, T, d, sc, &pos, st));
@@ -680,7 +679,7 @@ extern "C" int ns_op_duration_scan(const float* d_rounded, int B, int L, int32_t
   return 0;
 }
 extern "C" int ns_op_length_regulate(const float* x, const int32_t* cum, int B, int L, int D, int T, float* out, void* stream) {
-  NS_HIP(launch_length_regulate(x, cum, B, L, D, T, out, (hipStream_t)stream));
+  NS_HIP(launch_length_regulate(x, cum, B, L, D, T, out, nullptr, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ns_op_variance_embedding(ns_model* m, int which, const float* x, const int64_t* lens, int B, int S, float control,

@@ -49,7 +49,12 @@ hipError_t launch_mask_from_lengths(const long long* lens, int B, int max_len, u
 hipError_t launch_sinusoid(int n_pos, int d, float* out, hipStream_t st);
 hipError_t launch_duration_round(const float* log_d, int n, float d_control, float* d_rounded, hipStream_t st);
 hipError_t launch_duration_scan(const float* d_rounded, int B, int L, int32_t* cum, long long* mel_lens, hipStream_t st);
-hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int L, int D, int T, float* out, hipStream_t st);
+// mel_mask (nullable): also writes get_mask_from_lengths(mel_len) for the [B,T] frame grid
+hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int L, int D, int T, float* out, uint8_t* mel_mask,
+                                  hipStream_t st);
+// phase-1 tail in one launch: src mask, duration_round (two copies), duration_scan
+hipError_t launch_duration_tail(const float* log_d, const long long* src_lens, int B, int L, float d_control, float* d_rounded,
+                                float* d_keep, int32_t* cum, long long* mel_lens, uint8_t* src_mask, hipStream_t st);
 hipError_t launch_gaussian_upsampling(const float* x, const float* dur, int B, int L, int D, int T, int T_out,
                                       float* out, float* s, float* w, const long long* own_len, hipStream_t st);
 

@@ -295,16 +295,69 @@ hipError_t launch_duration_scan(const float* d_rounded, int B, int L, int32_t* c
   return hipGetLastError();
 }
 
+// The whole duration tail of phase 1 in ONE launch (what the four kernels above do one after the other; the forward
+// uses this, the per-op entry points keep the separate kernels): src mask, rounded durations (two copies: the caller's
+// output and the workspace copy phase 2 reads), truncated repeat counts, their prefix sums, mel_len.
+__global__ __launch_bounds__(256) void k_duration_tail(const float* __restrict__ log_d, const long long* __restrict__ src_lens,
+                                                        int L, float d_control, float* __restrict__ d_rounded,
+                                                        float* __restrict__ d_keep, int32_t* __restrict__ cum,
+                                                        long long* __restrict__ mel_lens, uint8_t* __restrict__ src_mask) {
+  __shared__ int wsum[4];
+  __shared__ int carry_s;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const long long len = src_lens[b];
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int l0 = 0; l0 < L; l0 += 256) {
+    const int l = l0 + tid;
+    int v = 0;
+    if (l < L) {
+      const size_t i = (size_t)b * L + l;
+      const float r = rintf(expf(log_d[i]) - 1.0f) * d_control;
+      const float dr = (r < 0.f) ? 0.f : r;
+      d_rounded[i] = dr;
+      d_keep[i] = dr;
+      src_mask[i] = (long long)l >= len ? 1 : 0;
+      const int ri = (int)dr;
+      v = ri > 0 ? ri : 0;
+    }
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int n = __shfl_up(inc, o);
+      if (lane >= o) inc += n;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    int off = carry_s;
+    for (int w = 0; w < wid; ++w) off += wsum[w];
+    if (l < L) cum[(size_t)b * L + l] = inc + off;
+    __syncthreads();
+    if (tid == 255) carry_s = inc + off;
+    __syncthreads();
+  }
+  if (tid == 0) mel_lens[b] = (long long)carry_s;
+}
+hipError_t launch_duration_tail(const float* log_d, const long long* src_lens, int B, int L, float d_control, float* d_rounded,
+                                float* d_keep, int32_t* cum, long long* mel_lens, uint8_t* src_mask, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_duration_tail, dim3(B), dim3(256), 0, st, log_d, src_lens, L, d_control, d_rounded, d_keep, cum, mel_lens,
+                     src_mask);
+  return hipGetLastError();
+}
+
 // LengthRegulator.LR + pad (model/modules.py:201-218, utils/tools.py:288-306) as a gather: output frame t of
 // utterance b copies encoder row i = first index with cum[b][i] > t; frames at t >= mel_len[b] are zero.
 __global__ __launch_bounds__(256) void k_length_regulate(const float* __restrict__ x, const int32_t* __restrict__ cum, int L,
-                                                          int D, int T, int M, float* __restrict__ out) {
+                                                          int D, int T, int M, float* __restrict__ out,
+                                                          uint8_t* __restrict__ mel_mask) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
   const int b = m / T, t = m % T;
   const int32_t* cb = cum + (size_t)b * L;
   const int total = L > 0 ? cb[L - 1] : 0;
+  if (mel_mask && lane == 0) mel_mask[m] = t >= total ? 1 : 0;  // get_mask_from_lengths(mel_len): total IS mel_len[b]
   float* dst = out + (size_t)m * D;
   if (t >= total) {
     for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<f32x4*>(dst + c) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -319,11 +372,12 @@ __global__ __launch_bounds__(256) void k_length_regulate(const float* __restrict
   const float* src = x + ((size_t)b * L + lo) * D;
   for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(src + c);
 }
-hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int L, int D, int T, float* out, hipStream_t st) {
+hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int L, int D, int T, float* out, uint8_t* mel_mask,
+                                  hipStream_t st) {
   const int M = B * T;
   if (M <= 0) return hipSuccess;
   if (D % 4 != 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_length_regulate, dim3((M + 3) / 4), dim3(256), 0, st, x, cum, L, D, T, M, out);
+  hipLaunchKernelGGL(k_length_regulate, dim3((M + 3) / 4), dim3(256), 0, st, x, cum, L, D, T, M, out, mel_mask);
   return hipGetLastError();
 }
 

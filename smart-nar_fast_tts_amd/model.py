@@ -230,7 +230,7 @@ class FastSpeech2Align:
             if callable(max_mel_len):
                 T = int(max_mel_len(out_mel_lens.max()))
             else:
-                T = int(out_mel_lens.max().item())
+                T = int(out_mel_lens.cpu().max()) if B <= 4096 else int(out_mel_lens.max().item())  # one small D2H copy
                 if max_mel_len is not None:
                     if int(max_mel_len) < T:
                         raise ValueError(f"max_mel_len ({int(max_mel_len)}) is smaller than the longest utterance ({T})")
