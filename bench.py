@@ -139,7 +139,7 @@ def main():
     if args.gpus == 1:
         # p50 per-utterance latency (the second half of BASELINE.json's metric), config 1: B=1, L=100
         c1, B1, L1, f1 = wl.WORKLOADS["cfg1_single"]
-        if c1 == cfg_name:
+        if c1 == cfg_name and f1 == fpp:  # same architecture AND same synthetic duration bias (mel_len 788)
             s1, t1, l1, _ = wl.synth_inputs(B1, L1, seed=0)
             a1 = [torch.from_numpy(a).to(dev) for a in (s1, t1, l1)]
             lat = []
