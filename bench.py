@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2_b16", help="cfg2_b16 | cfg4_d512 | cfg5_longform | cfg1_single")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="issue consecutive steps round-robin on this many HIP streams")
     ap.add_argument("--global-pad", action="store_true", help="pad every shard to the global max mel length (all-reduce MAX)")
     args = ap.parse_args()
 
@@ -67,8 +68,18 @@ def main():
     speakers, texts, src_lens = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (sp, tx, ln))
     pad_fn = sharding.global_max if (args.global_pad and world > 1) else None
 
+    # --streams S > 1: consecutive steps go round-robin onto S HIP streams, so the small-grid phase 1 of step i+1 (and
+    # the host read of mel_lens between the phases) overlaps the chip-filling phase 2 of step i.  Same K steps, same work.
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+    counter = [0]
+
     def step():
-        return model(speakers, texts, src_lens, Lmax, max_mel_len=pad_fn)
+        if streams is None:
+            return model(speakers, texts, src_lens, Lmax, max_mel_len=pad_fn)
+        st = streams[counter[0] % len(streams)]
+        counter[0] += 1
+        with torch.cuda.stream(st):
+            return model(speakers, texts, src_lens, Lmax, max_mel_len=pad_fn)
 
     def fence():
         torch.cuda.synchronize()

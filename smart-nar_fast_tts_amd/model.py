@@ -165,6 +165,9 @@ class FastSpeech2Align:
 
     # ---- forward -------------------------------------------------------------------------------
     def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
+        # one scratch set per (kind, stream): forwards issued on different streams may run concurrently on the GPU
+        # (batching.synthesize pipelines consecutive batches that way) and must not share temporaries
+        key = (key, torch.cuda.current_stream(self._device).cuda_stream)
         w = self._ws.get(key)
         if w is None or w.numel() < nbytes:
             w = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self._device)

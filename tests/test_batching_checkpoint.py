@@ -96,3 +96,28 @@ def test_checkpoint_file_round_trip_and_synthesize(tmp_path):
     with torch.no_grad():
         o1, o2 = model(*b0[2:]), direct(*b0[2:])
     assert torch.equal(o1[1], o2[1]) and torch.equal(o1[9], o2[9])
+
+
+@pytest.mark.gpu
+def test_stream_pipelined_synthesize_is_identical():
+    """synthesize(streams=3) runs consecutive batches concurrently on different HIP streams, each with its own
+    scratch: every per-utterance result must be bit-identical to the one-stream run (many small batches, several
+    rounds, so forwards really overlap and any shared temporary would show)."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd import batching
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    cfg = wl.model_config("tiny")
+    pc = wl.preprocess_config()
+    model = FastSpeech2Align(pc, cfg).to("cuda").eval()
+    model.load_state_dict(wl.synth_state_dict(cfg, frames_per_phoneme=6.0))
+    rng = np.random.RandomState(11)
+    data = [(f"utt{i}", 0, rng.randint(1, 300, size=int(rng.randint(5, 90))).astype(np.int64), "") for i in range(40)]
+    batchs = [batching.collate(data[i:i + 2]) for i in range(0, 40, 2)]
+    one = batching.synthesize(model, batchs, pc, "cuda")
+    for _ in range(3):
+        many = batching.synthesize(model, batchs, pc, "cuda", streams=3)
+        assert [r["basename"] for r in many] == [r["basename"] for r in one]
+        for a, b in zip(one, many):
+            assert a["mel_len"] == b["mel_len"] and torch.equal(a["mel"], b["mel"]), a["basename"]
+            assert np.array_equal(a["pitch"], b["pitch"]) and np.array_equal(a["duration"], b["duration"])
