@@ -373,7 +373,7 @@ static int check_ready(const ns_model* m) {
 static int gemm(const float* X, int ldx, const float* W, const float* bias, const float* resid, int ldr, float* Y, int ldy,
                 int M, int N, int Cin, int KW, int S, int act, hipStream_t st) {
   ConvGemm p;
-  p.X = X; p.ldx = ldx; p.W = W; p.bias = bias; p.resid = resid; p.ldr = ldr; p.Y = Y; p.ldy = ldy; p.lens = nullptr;
+  p.X = X; p.ldx = ldx; p.W = W; p.bias = bias; p.resid = resid; p.ldr = ldr; p.Y = Y; p.ldy = ldy;
   p.M = M; p.N = N; p.Cin = Cin; p.KW = KW; p.pad = (KW - 1) / 2; p.S = S; p.act = act;
   NS_HIP(launch_conv_gemm(p, st));
   return 0;

@@ -8,15 +8,13 @@ namespace ns {
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 
 // Y[m, n] = act( sum_{j<KW} sum_{c<Cin} X[m + j - pad, c] * W[n][j*Cin + c] + bias[n] ) + resid[m, n]
-// rows of X outside the utterance's [0, S) window read as zero ("same" zero padding of nn.Conv1d);
-// rows whose position t = m % S is >= lens[m / S] are written as zero when lens != nullptr.
+// rows of X outside the utterance's [0, S) window read as zero ("same" zero padding of nn.Conv1d).
 struct ConvGemm {
   const float* X; int ldx;
   const float* W;               // packed [N][KW*Cin]
   const float* bias;            // [N] or nullptr
   const float* resid; int ldr;  // [M, N] or nullptr
   float* Y; int ldy;
-  const long long* lens;        // [M / S] or nullptr
   int M, N, Cin, KW, pad, S;
   int act;
 };
