@@ -17,8 +17,10 @@ BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 python "$ROOT/bench.py" > "$OUT/${R}_bench.log" 2>&1
 tail -1 "$OUT/${R}_bench.log" > "$OUT/${R}_bench.json"
 
-rocprofv3 --kernel-trace --stats -d "$OUT/${R}_trace" -o t -- $BENCH > "$OUT/${R}_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format rocpd csv -d "$OUT/${R}_trace" -o t -- $BENCH > "$OUT/${R}_trace.log" 2>&1
 grep '^{' "$OUT/${R}_trace.log" | tail -1 > "$OUT/${R}_bench_under_trace.json"
+# rocprofv3's own per-kernel summary, as it wrote it (committed next to the per-geometry table make_profiles.py derives)
+find "$OUT/${R}_trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/${R}_rocprofv3_kernel_stats.csv" \;
 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/${R}_fetch" -o t -- $BENCH > "$OUT/${R}_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/${R}_write" -o t -- $BENCH > "$OUT/${R}_write.log" 2>&1

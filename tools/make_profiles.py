@@ -32,6 +32,10 @@ def pmc_rows(db):
 
 
 open(f"profiles/{ROUND}_kernel_stats.md", "w").write(run("tools/rocpd_stats.py", f"{G}/{ROUND}_trace/t_results.db"))
+import os
+import shutil
+if os.path.exists(f"{G}/{ROUND}_rocprofv3_kernel_stats.csv"):  # rocprofv3 --stats' own summary file, verbatim
+    shutil.copy(f"{G}/{ROUND}_rocprofv3_kernel_stats.csv", f"profiles/{ROUND}_rocprofv3_kernel_stats.csv")
 
 bench = json.load(open(f"{G}/{ROUND}_bench.json"))
 under = json.load(open(f"{G}/{ROUND}_bench_under_trace.json"))
