@@ -21,6 +21,12 @@ int main(int argc, char** argv) {
     {"pred conv   (k3 256->256)  M16160", 16160, 1010, 256, 3, 256},
     {"ffn_w1 enc  (k9 256->1024) M2048 ", 2048, 128, 256, 9, 1024},
     {"ffn_w1 d512 (k9 512->1024) M64640", 64640, 1010, 512, 9, 1024},
+    {"qkv d512    (k1 512->1536) M64640", 64640, 1010, 512, 1, 1536},
+    {"fc d512     (k1 512->512)  M64640", 64640, 1010, 512, 1, 512},
+    {"ffn_w2 d512 (k1 1024->512) M64640", 64640, 1010, 1024, 1, 512},
+    {"postnet mid (k5 512->512)  M64640", 64640, 1010, 512, 5, 512},
+    {"ffn_w1 long (k9 256->1024) M31200", 31200, 3900, 256, 9, 1024},
+    {"postnet mid (k5 512->512)  M31200", 31200, 3900, 512, 5, 512},
   };
   for (auto& s : shapes) {
     size_t nx = (size_t)s.M * s.Cin, nw = (size_t)s.N * s.KW * s.Cin, ny = (size_t)s.M * s.N;
