@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2_b16", help="cfg2_b16 | cfg4_d512 | cfg5_longform | cfg1_single")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ragged", action="store_true", help="ragged utterance lengths instead of the uniform BASELINE batch")
     ap.add_argument("--streams", type=int, default=1, help="issue consecutive steps round-robin on this many HIP streams")
     ap.add_argument("--global-pad", action="store_true", help="pad every shard to the global max mel length (all-reduce MAX)")
     args = ap.parse_args()
@@ -63,7 +64,12 @@ def main():
     sharding.broadcast_weights(model, sd, src=0)  # N == 1: plain load_state_dict
 
     # each rank's shard of the global batch (B_shard utterances per GPU): rows [rank*B, (rank+1)*B) of one seeded batch
-    sp, tx, ln, _ = wl.synth_inputs(B_shard * world, L, seed=0)
+    ragged = None
+    if args.ragged:  # phoneme counts uniform in [L/8, L], one utterance per shard at L: what unbucketed serving batches look like
+        rr = np.random.RandomState(7)
+        ragged = rr.randint(max(1, L // 8), L + 1, size=B_shard * world)
+        ragged[::B_shard] = L
+    sp, tx, ln, _ = wl.synth_inputs(B_shard * world, L, seed=0, src_lens=ragged)
     sp, tx, ln, Lmax = sharding.shard_batch(sp, tx, ln, world, rank)
     speakers, texts, src_lens = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (sp, tx, ln))
     pad_fn = sharding.global_max if (args.global_pad and world > 1) else None
@@ -132,7 +138,7 @@ def main():
         "metric": "mel_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: LJSpeech config, batch {B_shard}/GPU x {args.gpus} GPU, phoneme_len {L}, "
+        "config": {"workload": f"{args.workload}{' (ragged lengths)' if args.ragged else ''}: LJSpeech config, batch {B_shard}/GPU x {args.gpus} GPU, phoneme_len {L}, "
                                f"T_pad {T_pad_max}, d_model {cfg['transformer']['decoder_hidden']}, "
                                f"{cfg['transformer']['encoder_layer']}+{cfg['transformer']['decoder_layer']} FFT layers, "
                                f"random-init weights (seed 0, duration bias log({fpp + 1:g}))",

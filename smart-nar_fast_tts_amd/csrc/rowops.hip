@@ -62,11 +62,13 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
+  if (lens && (long long)(m % S) >= lens[m / S]) {  // masked_fill(mask, 0): a padded row is written, never read
+    for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<f32x4*>(y + (size_t)m * C + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
   f32x4 v[NV];
   float mean, rstd;
   ln_stats<NV>(x + (size_t)m * C, C, lane, v, mean, rstd);
-  bool pad = false;
-  if (lens) pad = (long long)(m % S) >= lens[m / S];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + i * 256;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
       const f32x4 bb = *reinterpret_cast<const f32x4*>(bta + c);
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = pad ? 0.f : (v[i][e] - mean) * rstd * gg[e] + bb[e];
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
       *reinterpret_cast<f32x4*>(y + (size_t)m * C + c) = o;
     }
   }

@@ -504,3 +504,29 @@ def test_large_batch_replicas_are_identical():
     for i in (0, 1):
         err = (big[i][:16] - small_p[i]).abs().cpu().numpy()[valid].max()
         assert err < 2e-5, (NAMES[i], err)
+
+
+def test_ragged_batch_vs_oracle():
+    """Ragged batch at the LJSpeech widths: one long utterance sets T_pad ~ 1000 while the others leave hundreds of
+    padded frames (whole GEMM tiles and attention query/key tiles of padding, masked LayerNorm rows that are written
+    without being read).  Every output row — padded ones included — must match the oracle."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from oracle import fs2_oracle as orc
+
+    meta = dict(config="ljspeech", weight_seed=0, frames_per_phoneme=8.0, dur_weight_scale=0.25)
+    cfg, sd, m = gpu_model(meta)
+    lens = np.array([128, 10, 64, 1, 100, 33, 127, 17])
+    inp = wl.synth_inputs(len(lens), 128, seed=9, src_lens=lens)
+    w = orc.to_torch_weights(sd)
+    with torch.no_grad():
+        ref = orc.forward(w, cfg, torch.from_numpy(inp[0]), torch.from_numpy(inp[1]), torch.from_numpy(inp[2]), inp[3])
+        out = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3])
+    assert np.array_equal(out[5].cpu().numpy(), ref[5].numpy()), "durations differ"
+    assert np.array_equal(out[9].cpu().numpy(), ref[9].numpy())
+    assert int(ref[9].max()) > 900 and int(ref[9].min()) < 16
+    with torch.no_grad():
+        tf = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3], p_targets=ref[2].cuda(), e_targets=ref[3].cuda())
+    close(tf[4], ref[4].numpy(), 1e-4, "log durations")
+    close(tf[3], ref[3].numpy(), MEL_TOL, "energy")
+    print("ragged: mel", close(tf[0], ref[0].numpy(), MEL_TOL, "mel (all rows, padded included)"),
+          "postnet", close(tf[1], ref[1].numpy(), MEL_TOL, "postnet mel (all rows, padded included)"))
