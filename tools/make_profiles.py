@@ -39,6 +39,25 @@ if os.path.exists(f"{G}/{ROUND}_rocprofv3_kernel_stats.csv"):  # rocprofv3 --sta
 
 bench = json.load(open(f"{G}/{ROUND}_bench.json"))
 under = json.load(open(f"{G}/{ROUND}_bench_under_trace.json"))
+
+# The dominant kernel's launches inside the TIMED region of the traced run (rocprofv3's table averages the warm-up
+# launches in as well): the last `launches` dispatches of the biggest-grid k_conv_gemm, to set beside bench.py's
+# HIP-event average of the same launches in the same process.
+import sqlite3
+con = sqlite3.connect(f"{G}/{ROUND}_trace/t_results.db")
+rows = con.execute("select start, end, grid_x / workgroup_x as wgs from kernels where name like '%k_conv_gemm<64, 256, 32, 1, 2, 4>%' order by start").fetchall()
+if rows:
+    big = max(r[2] for r in rows)
+    durs = [(r[1] - r[0]) / 1e3 for r in rows if r[2] == big]
+    n = int(under["roofline"]["launches"])
+    timed = durs[-n:]
+    under["rocprofv3_same_launches"] = {"kernel_workgroups": int(big), "launches": len(timed),
+                                        "avg_us": round(sum(timed) / len(timed), 1),
+                                        "hip_event_avg_us_in_bench": round(under["roofline"]["avg_launch_ms"] * 1e3, 1)}
+    with open(f"profiles/{ROUND}_kernel_stats.md", "a") as fh:
+        fh.write(f"\nDominant kernel, timed region only (last {len(timed)} of {len(durs)} launches of the {int(big)}-workgroup "
+                 f"`k_conv_gemm<64, 256, 32, 1, 2, 4>`): rocprofv3 avg {sum(timed) / len(timed):.1f} us; bench.py's HIP events "
+                 f"around the same launches in the same process: {under['roofline']['avg_launch_ms'] * 1e3:.1f} us.\n")
 json.dump({"bench": bench, "bench_under_kernel_trace": under}, open(f"profiles/{ROUND}_bench.json", "w"), indent=1)
 
 # the dominant kernel = the most expensive (kernel, grid) of the trace
