@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2_b16", help="cfg2_b16 | cfg4_d512 | cfg5_longform | cfg1_single")
+    ap.add_argument("--workload", default="cfg2_b16", help="cfg2_b16 | cfg4_d512 | cfg5_longform | cfg5_longform_gaussian | cfg1_single")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ragged", action="store_true", help="ragged utterance lengths instead of the uniform BASELINE batch")
     ap.add_argument("--streams", type=int, default=1, help="issue consecutive steps round-robin on this many HIP streams")
@@ -180,11 +180,12 @@ def main():
         torch.set_num_threads(cores)
         w = orc.to_torch_weights(wl.synth_state_dict(cfg, seed=0, frames_per_phoneme=fpp))
         ci = [torch.from_numpy(np.ascontiguousarray(a)) for a in (sp, tx, ln)]
+        lr = cfg.get("length_regulator", "hard")
         with torch.no_grad():
-            ref = orc.forward(w, cfg, ci[0], ci[1], ci[2], Lmax)  # warm-up
+            ref = orc.forward(w, cfg, ci[0], ci[1], ci[2], Lmax, length_regulator=lr)  # warm-up
             n, t0 = 0, time.perf_counter()
             while n < 5 and (time.perf_counter() - t0) < 20.0:
-                ref = orc.forward(w, cfg, ci[0], ci[1], ci[2], Lmax)
+                ref = orc.forward(w, cfg, ci[0], ci[1], ci[2], Lmax, length_regulator=lr)
                 n += 1
             cpu_t = (time.perf_counter() - t0) / n
         cpu_frames = orc.valid_frames(ref)

@@ -73,6 +73,10 @@ def model_config(name: str = "ljspeech") -> dict:
     mc = copy.deepcopy(LJSPEECH_MODEL_CONFIG)
     if name == "ljspeech":
         return mc
+    if name.endswith("+gaussian"):
+        mc = model_config(name[:-len("+gaussian")])
+        mc["length_regulator"] = "gaussian"
+        return mc
     if name == "d512":  # BASELINE config 4: d_model=512, 6+6 layers, 8 heads
         t = mc["transformer"]
         t.update(encoder_layer=6, decoder_layer=6, encoder_head=8, decoder_head=8,
@@ -238,6 +242,9 @@ WORKLOADS = {
     "cfg3_b128_sharded": ("ljspeech", 128, 128, 8.0),
     "cfg4_d512": ("d512", 64, 128, 8.0),
     "cfg5_longform": ("ljspeech", 8, 128, 31.0),
+    # config 5 names "Gaussian-upsample": the same batch with the reference's (unwired) GaussianUpsampling module as
+    # the length regulator — the extension of SURVEY.md §8 f1; the plain cfg5_longform is the reference's real path
+    "cfg5_longform_gaussian": ("ljspeech+gaussian", 8, 128, 31.0),
 }
 
 
