@@ -30,6 +30,7 @@ int main(int argc, char** argv) {
     {"qkv dec     (k1 256->768) ", 16160, 1010, 256, 1, 768},
     {"pred conv   (k3 256->256) ", 16160, 1010, 256, 3, 256},
     {"ffn_w1 enc  (k9 256->1024)", 2048, 128, 256, 9, 1024},
+    {"fc dec      (k1 256->256) ", 16160, 1010, 256, 1, 256},
   };
   for (auto& s : shapes) {
     size_t nx = (size_t)s.M * s.Cin, nw = (size_t)s.N * s.KW * s.Cin, ny = (size_t)s.M * s.N;
@@ -47,7 +48,7 @@ int main(int argc, char** argv) {
     printf("%s  %.1f GFLOP\n", s.name, gf);
 #define RUN(BM, BN, BK) { float ms = time_variant<BM, BN, BK>(p, 10); printf("   %3dx%3dx%2d  %8.1f us  %6.1f TF/s\n", BM, BN, BK, ms * 1e3, gf / ms); }
 #define RUNW(BM, BN, BK, WGM, WGN) { float ms = time_variant<BM, BN, BK, WGM, WGN>(p, 10); printf("   %3dx%3dx%2d waves %dx%d %8.1f us  %6.1f TF/s\n", BM, BN, BK, WGM, WGN, ms * 1e3, gf / ms); }
-    RUNW(64, 128, 32, 2, 4) RUNW(64, 128, 32, 2, 2) RUNW(128, 128, 32, 4, 4) RUNW(64, 256, 32, 2, 8) RUNW(64, 256, 32, 2, 4) RUNW(128, 64, 32, 4, 2) RUNW(64, 64, 32, 2, 2) RUNW(32, 256, 32, 1, 8) RUNW(128, 256, 32, 4, 4)
+    RUNW(64, 128, 32, 2, 4) RUNW(64, 128, 32, 2, 2) RUNW(128, 128, 32, 4, 4) RUNW(64, 256, 32, 2, 8) RUNW(64, 256, 32, 2, 4) RUNW(128, 64, 32, 4, 2) RUNW(64, 64, 32, 2, 2) RUNW(32, 256, 32, 1, 8) RUNW(128, 256, 32, 4, 4) RUNW(32, 128, 32, 1, 4) RUNW(32, 64, 32, 1, 2) RUNW(64, 64, 32, 2, 2)
 #ifdef NS_LAB_EXTRA
     NS_LAB_EXTRA
 #endif
