@@ -38,7 +38,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-constexpr int OOR = (int)0x80000000;  // voffset marker: beyond num_records -> the DMA writes zeros
+[[maybe_unused]] constexpr int OOR = (int)0x80000000;  // voffset marker: beyond num_records -> the DMA writes zeros
 
 template <int BM, int BN, int BK, int KS, int WGM = 2, int WGN = 2>
 __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, int ntn) {
