@@ -225,6 +225,8 @@ def position_switch_case():
 def baseline_size_pins():
     # BASELINE.json configs at full size: integer outputs in full, mel sub-sampled (every 16th frame)
     for name, (cfgname, B, L, fpp) in wl.WORKLOADS.items():
+        if "+" in cfgname:
+            continue  # extension workloads (Gaussian regulator wired in): the reference forward has no such switch
         if name == "cfg3_b128_sharded":
             B = 16  # one rank's shard of config 3 == config 2 with another input seed
         if name == "cfg4_d512":
