@@ -87,6 +87,13 @@ def model_config(name: str = "ljspeech") -> dict:
         t = mc["transformer"]
         t.update(encoder_layer=1, decoder_layer=1)
         return mc
+    if name in ("tiny512", "tiny_h4"):  # fuzzing: the d_k = 64 / d_k = 32 attention paths and 512-wide rows, 1+1 layers
+        t = mc["transformer"]
+        if name == "tiny512":
+            t.update(encoder_layer=1, decoder_layer=1, encoder_head=8, decoder_head=8, encoder_hidden=512, decoder_hidden=512)
+        else:
+            t.update(encoder_layer=1, decoder_layer=1, encoder_head=8, decoder_head=4)  # 256 wide: d_k 32 / 64
+        return mc
     raise KeyError(name)
 
 
