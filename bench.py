@@ -25,6 +25,12 @@ import torch  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix), v_mfma_f32_32x32x2_f32
 HBM_PEAK_GBS = 8000.0
+# the same two ceilings measured on an MI355X box with microbenchmarks (tools/lab/mfma_peak.hip, tools/lab/dma_fill.hip)
+F32_MFMA_MEASURED_TFLOPS = 155.0
+HBM_MEASURED_GBS = 6400.0
+# SURVEY.md §8(d) algorithmic bytes per valid frame (weights once per forward + every sub-layer boundary tensor once each way)
+ALGORITHMIC_KB_PER_FRAME = {"cfg1_single": 190.0, "cfg2_b16": 77.0, "cfg3_b128_sharded": 77.0, "cfg4_d512": 174.0,
+                            "cfg5_longform": 70.0, "cfg5_longform_gaussian": 70.0}
 
 
 def main():
@@ -149,9 +155,20 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "k_conv_gemm (FFN w_1: Conv1d k=9, d->d_inner, bias+ReLU)",
                      "achieved": round(achieved_tflops, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved_tflops / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                     "frac_of_measured_peak": round(achieved_tflops / F32_MFMA_MEASURED_TFLOPS, 4),
                      "launches": int(k_launches), "avg_launch_ms": round(k_ms / max(k_launches, 1), 4),
                      "share_of_step_time": round((k_ms * 1e-3) / elapsed if elapsed > 0 else 0.0, 3)},
     }
+
+    # whole forward against both ceilings (MFMA primary, HBM secondary; vendor and measured peaks), per GPU
+    kb = ALGORITHMIC_KB_PER_FRAME.get(args.workload)
+    e2e_tf = flops_frame * value / 1e12 / args.gpus
+    res["end_to_end"] = {"tflops_per_gpu": round(e2e_tf, 2), "frac_mfma_peak": round(e2e_tf / F32_MFMA_PEAK_TFLOPS, 4),
+                         "frac_mfma_measured": round(e2e_tf / F32_MFMA_MEASURED_TFLOPS, 4),
+                         "algorithmic_kb_per_frame": kb,
+                         "hbm_gbs_per_gpu": None if kb is None else round(kb * 1e3 * value / args.gpus / 1e9, 1),
+                         "frac_hbm_peak": None if kb is None else round(kb * 1e3 * value / args.gpus / 1e9 / HBM_PEAK_GBS, 4),
+                         "frac_hbm_measured": None if kb is None else round(kb * 1e3 * value / args.gpus / 1e9 / HBM_MEASURED_GBS, 4)}
 
     if args.gpus == 1:
         # p50 per-utterance latency (the second half of BASELINE.json's metric), config 1: B=1, L=100
