@@ -54,14 +54,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # NS_BENCH_ONE_GPU=1 (test rigs only): every rank on cuda:0 with gloo, to exercise the N > 1 flow on a one-GPU box
+    one_gpu = os.environ.get("NS_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     cfg_name, B_shard, L, fpp = wl.WORKLOADS[args.workload]
     cfg = wl.model_config(cfg_name)

@@ -67,3 +67,83 @@ def test_two_rank_gloo():
     for rank, ok_bcast, span, same_rows, same_L, gmax in res:
         assert ok_bcast and same_rows and same_L
         assert gmax == 110  # max(100, 110)
+
+
+def _gpu_worker(rank, world, port, q):
+    """bench.py's N > 1 flow with both ranks on cuda:0 and gloo instead of RCCL: rank 0 packs the weights, ONE broadcast
+    of the arena bytes, the other rank adopts them, every rank runs its own shard."""
+    import numpy as np
+
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd import sharding
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        cfg = wl.model_config("tiny")
+        model = FastSpeech2Align(wl.preprocess_config(), cfg).to(dev).eval()
+        sd = wl.synth_state_dict(cfg, seed=0, frames_per_phoneme=4.0) if rank == 0 else None
+        arena = model.arena_tensor()
+        try:
+            sharding.broadcast_weights(model, sd, src=0)
+        except RuntimeError:  # a gloo build without device-tensor support: stage the same bytes through the host
+            if rank == 0:
+                model.load_state_dict(sd)
+            host = model.arena_tensor().cpu()
+            sharding.broadcast_bytes(host, src=0)
+            model.arena_tensor().copy_(host)
+            if rank != 0:
+                model.adopt_arena()
+        assert model.arena_tensor().data_ptr() == arena.data_ptr() or rank == 0
+        sp, tx, ln, _ = wl.synth_inputs(6, 40, seed=3)
+        s_sp, s_tx, s_ln, L = sharding.shard_batch(sp, tx, ln, world, rank)
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        with torch.no_grad():
+            out = model(to(s_sp), to(s_tx), to(s_ln), L)
+            # global-pad mode: every shard pads to the global longest mel
+            outg = model(to(s_sp), to(s_tx), to(s_ln), L, max_mel_len=sharding.global_max)
+        torch.cuda.synchronize()
+        q.put((rank, out[1].cpu().numpy(), out[9].cpu().numpy(), int(outg[1].shape[1])))
+    finally:
+        dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_rank_weight_broadcast_and_shards_on_gpu():
+    """The multi-GPU flow end to end on the one GPU a test box has: the rank that ADOPTED the broadcast arena must produce
+    exactly what a single process with the state dict loaded produces on the same shard."""
+    import numpy as np
+
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd import sharding
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    cfg = wl.model_config("tiny")
+    model = FastSpeech2Align(wl.preprocess_config(), cfg).to("cuda").eval()
+    model.load_state_dict(wl.synth_state_dict(cfg, seed=0, frames_per_phoneme=4.0))
+    sp, tx, ln, _ = wl.synth_inputs(6, 40, seed=3)
+    tmax = 0
+    for rank, post, mel_lens, t_global in res:
+        s_sp, s_tx, s_ln, L = sharding.shard_batch(sp, tx, ln, world, rank)
+        with torch.no_grad():
+            ref = model(*(torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (s_sp, s_tx, s_ln)), L)
+        assert np.array_equal(mel_lens, ref[9].cpu().numpy())
+        assert np.array_equal(post, ref[1].cpu().numpy()), f"rank {rank}: adopted weights give different bits"
+        tmax = max(tmax, int(mel_lens.max()))
+    assert all(r[3] == tmax for r in res), "global-pad mode: every shard pads to the global longest mel"
