@@ -2,7 +2,7 @@
 """Long randomized parity run of the HIP path against the oracle (run it on the GPU box; not part of the test suite,
 which holds a short version: tests/test_gpu_parity.py::test_random_shapes_vs_oracle).
 
-    gpurun -- 'python tools/fuzz_gpu.py --iters 150 --seed 1'
+    gpurun -- 'python tests/fuzz_gpu.py --iters 150 --seed 1'
 
 Each iteration draws a model shape (tiny / tiny512 / tiny_h4: 1+1 layers, d_k 128 / 64 / 32), feature levels, the length
 regulator, control factors, a batch shape with ragged lengths, and checks: log-durations, exact durations and frame
@@ -14,7 +14,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
