@@ -110,11 +110,18 @@ def main():
             out = step()
         fence()
         model.profile_dominant_kernel(True)
+        # per-step spread without extra syncs: one event per step on the launch stream, read after the closing fence
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if streams is None else None
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        if marks:
+            marks[0].record()
+        for i in range(args.steps):
             out = step()
+            if marks:
+                marks[i + 1].record()
         fence()
         elapsed = time.perf_counter() - t0
+        step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)) if marks else None
         k_ms, k_flops, k_launches = model.read_profile()
         model.profile_dominant_kernel(False)
 
@@ -176,6 +183,9 @@ def main():
                          "frac_hbm_peak": None if kb is None else round(kb * 1e3 * value / args.gpus / 1e9 / HBM_PEAK_GBS, 4),
                          "frac_hbm_measured": None if kb is None else round(kb * 1e3 * value / args.gpus / 1e9 / HBM_MEASURED_GBS, 4)}
 
+    if step_ms:
+        res["step_ms_spread"] = {"p50": round(step_ms[len(step_ms) // 2], 3), "min": round(step_ms[0], 3),
+                                 "max": round(step_ms[-1], 3), "n": len(step_ms)}
     if args.gpus == 1:
         # p50 per-utterance latency (the second half of BASELINE.json's metric), config 1: B=1, L=100
         c1, B1, L1, f1 = wl.WORKLOADS["cfg1_single"]
