@@ -25,6 +25,10 @@ int main(int argc, char** argv) {
     {"fc d512     (k1 512->512)  M64640", 64640, 1010, 512, 1, 512},
     {"ffn_w2 d512 (k1 1024->512) M64640", 64640, 1010, 1024, 1, 512},
     {"postnet mid (k5 512->512)  M64640", 64640, 1010, 512, 5, 512},
+    {"postnet L   (k5 512->80)   M16160", 16160, 1010, 512, 5, 80},
+    {"postnet L   (k5 512->80)   M31200", 31200, 3900, 512, 5, 80},
+    {"postnet L   (k5 512->80)   M64640", 64640, 1010, 512, 5, 80},
+    {"mel_linear  (k1 256->80)   M16160", 16160, 1010, 256, 1, 80},
     {"ffn_w1 long (k9 256->1024) M31200", 31200, 3900, 256, 9, 1024},
     {"postnet mid (k5 512->512)  M31200", 31200, 3900, 512, 5, 512},
   };
