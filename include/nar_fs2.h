@@ -73,6 +73,8 @@ size_t ns_decoder_ws_bytes(const ns_model* m, int B, int L, int T);
 /* Phase 1: get_mask_from_lengths + TxtEncoder + duration predictor + rounding + duration scan.
  * Writes log_d [B,L], d_rounded [B,L] (float32, may hold -0.0), src_mask [B,L], mel_lens [B] (int64).
  * The encoder output and the duration prefix sums stay in ws_enc for phase 2.
+ * A token id outside [0, n_vocab) (nn.Embedding raises IndexError, transformer/Models.py:89) is reported as
+ * mel_lens[b] = -1 for its utterance; the kernels read embedding row 0 for it, nothing out of bounds.
  * The caller reads mel_lens back (the one unavoidable device->host read: the output tensors are
  * shaped by max(mel_lens), model/modules.py:136-137) and allocates the phase-2 outputs. */
 /* phoneme_level pitch / energy (preprocess.yaml `feature`, model/modules.py:117-126) are predicted here, on the
@@ -142,12 +144,18 @@ int ns_op_ffn_conv1(ns_model* m, const char* prefix, const float* x, int B, int 
 int ns_op_attention_core(const float* qkv, const int64_t* lens, int B, int S, int H, int dk, float* out, void* scratch,
                          size_t scratch_bytes, void* stream);
 
-/* Measurement hook for bench.py's roofline leg: while enabled, every launch of the dominant kernel (the FFT blocks'
- * k=9 Conv1D-as-GEMM, PositionwiseFeedForward.w_1, transformer/SubLayers.py:70-75) inside ns_forward_* is bracketed
- * by hipEvents on the launch stream.  ns_profile_read waits for them and returns the summed kernel time, the summed
- * algorithmic flops (2*rows*k*d*d_inner per launch) and the launch count, then resets the counters. */
+/* Measurement hook for bench.py's roofline legs: while enabled, the launches of the three heaviest kernels inside
+ * ns_forward_mel are bracketed by hipEvents on the launch stream, one slot each:
+ *   slot 0  the FFT blocks' k=9 Conv1D-as-GEMM (PositionwiseFeedForward.w_1, transformer/SubLayers.py:70-75; the dominant
+ *           kernel): flops = 2*rows*k*d*d_inner per launch
+ *   slot 1  the fused attention (transformer/Modules.py:14-25): flops = 4*rows*T*d per launch
+ *   slot 2  the PostNet's 512->512 k=5 convolutions (transformer/Layers.py:120-152): flops = 2*rows*k*512*512 per launch
+ * ns_profile_read_slot waits for the slot's events and returns the summed kernel time, the summed algorithmic flops and
+ * the launch count, then resets the slot.  ns_profile_read is slot 0. */
+#define NS_PROFILE_SLOTS 3
 int ns_profile_enable(ns_model* m, int on);
 int ns_profile_read(ns_model* m, double* total_ms, double* total_flops, int64_t* launches);
+int ns_profile_read_slot(ns_model* m, int slot, double* total_ms, double* total_flops, int64_t* launches);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,7 @@ SIGNATURES = {
     "ns_op_attention_core": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _Z, _P]),
     "ns_profile_enable": (_I, [_P, _I]),
     "ns_profile_read": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "ns_profile_read_slot": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 _lib = None

@@ -34,7 +34,8 @@ def _stale(target: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "kernels.h"), os.path.join(os.path.dirname(HERE), "include", "nar_fs2.h")]
+    headers = sorted(os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h"))
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "nar_fs2.h"))
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

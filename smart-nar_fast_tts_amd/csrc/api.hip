@@ -52,11 +52,12 @@ struct ns_model {
   bool ready = false;
   std::map<std::string, Staged> staged;
   const float* P(size_t off) const { return arena + off; }
-  // optional HIP-event timing of the dominant kernel (FFN k=9 Conv1D-as-GEMM) inside the real forward
-  bool prof = false, prof_active = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
-  size_t prof_used = 0;
-  double prof_flops = 0.0;
+  // optional HIP-event timing of the three heaviest launch groups inside the real forward (bench.py's roofline legs):
+  // slot 0 = FFN w_1 (k=9 Conv1D-as-GEMM, the dominant kernel), 1 = fused attention, 2 = PostNet 512->512 k=5 layers.
+  // Measurement state, not model state: mutable so that the (const) forward helpers can record into it.
+  struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double flops = 0.0; };
+  mutable bool prof = false, prof_active = false;
+  mutable ProfSlot prof_slot[NS_PROFILE_SLOTS];
 };
 
 static const char* kPredNames[3] = {"duration", "pitch", "energy"};
@@ -165,7 +166,12 @@ extern "C" int ns_create(const ns_config* cfg, ns_model** out) {
   return 0;
 }
 
-extern "C" void ns_destroy(ns_model* m) { delete m; }
+extern "C" void ns_destroy(ns_model* m) {
+  if (!m) return;
+  for (auto& ps : m->prof_slot)
+    for (auto& ev : ps.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  delete m;
+}
 extern "C" size_t ns_arena_bytes(const ns_model* m) { return m ? m->ar.n * sizeof(float) : 0; }
 
 extern "C" int ns_bind_arena(ns_model* m, void* dev, size_t bytes) {
@@ -371,23 +377,81 @@ static int check_ready(const ns_model* m) {
 }
 
 static int gemm(const float* X, int ldx, const float* W, const float* bias, const float* resid, int ldr, float* Y, int ldy,
-                int M, int N, int Cin, int KW, int S, int act, hipStream_t st) {
+                int M, int N, int Cin, int KW, int S, int act, hipStream_t st, const RowEpilogue* epi = nullptr, int epi_mode = EPI_NONE) {
   ConvGemm p;
+  memset(&p, 0, sizeof(p));
   p.X = X; p.ldx = ldx; p.W = W; p.bias = bias; p.resid = resid; p.ldr = ldr; p.Y = Y; p.ldy = ldy;
   p.M = M; p.N = N; p.Cin = Cin; p.KW = KW; p.pad = (KW - 1) / 2; p.S = S; p.act = act;
+  p.epi = epi ? epi_mode : EPI_NONE;
+  if (epi) p.e = *epi;
   NS_HIP(launch_conv_gemm(p, st));
   return 0;
 }
 
-// MultiHeadAttention.forward (transformer/SubLayers.py:29-59); out = LayerNorm(fc(attn) + x), NOT yet masked
+// A GEMM whose N columns are one whole activation row can run the row's LayerNorm in its epilogue (kernels.h
+// RowEpilogue).  The full-row tile is 32 rows tall, so it is taken once the launch has about a workgroup per CU;
+// below that the many-small-tiles + split-K ladder followed by the row kernel is faster (tools/lab/gemm_lab_ln.hip:
+// M=16160 K=1024 93 -> 85 us, K=256 39.5 -> 31 us; M=2048 K=1024 21.6 -> 43 us).
+static bool fuse_row_epilogue(int M, int N, int Cin) {
+  return conv_gemm_row_epilogue_ok(M, N, Cin) && (M + 31) / 32 >= 200;
+}
+
+// Y = mask(LayerNorm(act(conv(X)) + resid)): one launch when the full-row tile applies, else GEMM -> tmp -> k_layernorm
+static int gemm_ln(const float* X, int ldx, const float* W, const float* bias, const float* resid, float* tmp, float* Y,
+                   int M, int N, int Cin, int KW, int S, int act, const float* g, const float* b, const long long* lens,
+                   hipStream_t st) {
+  if (fuse_row_epilogue(M, N, Cin)) {
+    RowEpilogue e;
+    memset(&e, 0, sizeof(e));
+    e.ln_g = g; e.ln_b = b; e.lens = lens;
+    return gemm(X, ldx, W, bias, resid, N, Y, N, M, N, Cin, KW, S, act, st, &e, EPI_LN);
+  }
+  NS_TRY(gemm(X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st));
+  NS_HIP(launch_layernorm(tmp, g, b, Y, M, N, S, lens, st));
+  return 0;
+}
+
+// HIP-event bracket around one launch group on the launch stream; a no-op unless ns_profile_enable(1) and the
+// forward is inside its timed section (the decoder stack / PostNet of ns_forward_mel)
+struct ProfScope {
+  const ns_model* m; int slot; hipStream_t st; double flops; bool on;
+  ProfScope(const ns_model* m_, int slot_, hipStream_t st_, double flops_)
+      : m(m_), slot(slot_), st(st_), flops(flops_), on(m_->prof_active) {}
+  int begin() {
+    if (!on) return 0;
+    ns_model::ProfSlot& ps = m->prof_slot[slot];
+    if (ps.used == ps.ev.size()) {
+      hipEvent_t a, b;
+      NS_HIP(hipEventCreate(&a));
+      NS_HIP(hipEventCreate(&b));
+      ps.ev.emplace_back(a, b);
+    }
+    NS_HIP(hipEventRecord(ps.ev[ps.used].first, st));
+    return 0;
+  }
+  int end() {
+    if (!on) return 0;
+    ns_model::ProfSlot& ps = m->prof_slot[slot];
+    NS_HIP(hipEventRecord(ps.ev[ps.used].second, st));
+    ps.used++;
+    ps.flops += flops;
+    return 0;
+  }
+};
+
+// MultiHeadAttention.forward (transformer/SubLayers.py:29-59); out = LayerNorm(fc(attn) + x), masked when mask_rows
 static int mha(const ns_model* m, const LayerW& L, int d, int H, const float* x, const long long* lens, int B, int S,
                float* out, bool mask_rows, Scratch& sc, hipStream_t st) {
   const int M = B * S;
   NS_TRY(gemm(x, d, m->P(L.qkv_w), m->P(L.qkv_b), nullptr, 0, sc.qkv, 3 * d, M, 3 * d, d, 1, S, ACT_NONE, st));
-  NS_HIP(launch_attention(sc.qkv, lens, B, S, H, d / H, sc.att, sc.att_part, sc.att_part_floats, st));
-  NS_TRY(gemm(sc.att, d, m->P(L.fc_w), m->P(L.fc_b), x, d, sc.t1, d, M, d, d, 1, S, ACT_NONE, st));
-  NS_HIP(launch_layernorm(sc.t1, m->P(L.ln1_g), m->P(L.ln1_b), out, M, d, S, mask_rows ? lens : nullptr, st));
-  return 0;
+  {
+    ProfScope ps(m, 1, st, 4.0 * (double)M * (double)S * (double)d);
+    NS_TRY(ps.begin());
+    NS_HIP(launch_attention(sc.qkv, lens, B, S, H, d / H, sc.att, sc.att_part, sc.att_part_floats, st));
+    NS_TRY(ps.end());
+  }
+  return gemm_ln(sc.att, d, m->P(L.fc_w), m->P(L.fc_b), x, sc.t1, out, M, d, d, 1, S, ACT_NONE, m->P(L.ln1_g), m->P(L.ln1_b),
+                 mask_rows ? lens : nullptr, st);
 }
 
 // PositionwiseFeedForward.forward (transformer/SubLayers.py:87-95)
@@ -395,26 +459,14 @@ static int ffn(const ns_model* m, const LayerW& L, int d, const float* x, const 
                bool mask_rows, Scratch& sc, hipStream_t st) {
   const ns_config& c = m->cfg;
   const int M = B * S;
-  ns_model* mm = const_cast<ns_model*>(m);
-  const bool prof = m->prof_active;
-  if (prof) {
-    if (mm->prof_used == mm->prof_ev.size()) {
-      hipEvent_t a, b;
-      NS_HIP(hipEventCreate(&a));
-      NS_HIP(hipEventCreate(&b));
-      mm->prof_ev.emplace_back(a, b);
-    }
-    NS_HIP(hipEventRecord(mm->prof_ev[mm->prof_used].first, st));
+  {
+    ProfScope ps(m, 0, st, 2.0 * (double)M * (double)c.ffn_k1 * (double)d * (double)c.d_inner);
+    NS_TRY(ps.begin());
+    NS_TRY(gemm(x, d, m->P(L.w1), m->P(L.w1_b), nullptr, 0, sc.hid, c.d_inner, M, c.d_inner, d, c.ffn_k1, S, ACT_RELU, st));
+    NS_TRY(ps.end());
   }
-  NS_TRY(gemm(x, d, m->P(L.w1), m->P(L.w1_b), nullptr, 0, sc.hid, c.d_inner, M, c.d_inner, d, c.ffn_k1, S, ACT_RELU, st));
-  if (prof) {
-    NS_HIP(hipEventRecord(mm->prof_ev[mm->prof_used].second, st));
-    mm->prof_used++;
-    mm->prof_flops += 2.0 * (double)M * (double)c.ffn_k1 * (double)d * (double)c.d_inner;
-  }
-  NS_TRY(gemm(sc.hid, c.d_inner, m->P(L.w2), m->P(L.w2_b), x, d, sc.t1, d, M, d, c.d_inner, c.ffn_k2, S, ACT_NONE, st));
-  NS_HIP(launch_layernorm(sc.t1, m->P(L.ln2_g), m->P(L.ln2_b), out, M, d, S, mask_rows ? lens : nullptr, st));
-  return 0;
+  return gemm_ln(sc.hid, c.d_inner, m->P(L.w2), m->P(L.w2_b), x, sc.t1, out, M, d, c.d_inner, c.ffn_k2, S, ACT_NONE, m->P(L.ln2_g),
+                 m->P(L.ln2_b), mask_rows ? lens : nullptr, st);
 }
 
 // FFTBlock.forward (transformer/Layers.py:39-48): both masked_fill's are fused into the LayerNorm kernels
@@ -443,8 +495,19 @@ static int predictor(const ns_model* m, const PredW& w, const float* x, const lo
                      hipStream_t st) {
   const ns_config& c = m->cfg;
   const int M = B * S, F = c.vp_filter;
-  NS_TRY(gemm(x, w.cin, m->P(w.c1), m->P(w.c1_b), nullptr, 0, sc.vp1, F, M, F, w.cin, c.vp_kernel, S, ACT_RELU, st));
-  NS_HIP(launch_layernorm(sc.vp1, m->P(w.ln1_g), m->P(w.ln1_b), sc.vp2, M, F, S, nullptr, st));
+  // conv1d_1 -> relu -> layer_norm_1 (no mask between the layers: model/modules.py:245-274)
+  NS_TRY(gemm_ln(x, w.cin, m->P(w.c1), m->P(w.c1_b), nullptr, sc.vp1, sc.vp2, M, F, w.cin, c.vp_kernel, S, ACT_RELU, m->P(w.ln1_g),
+                 m->P(w.ln1_b), nullptr, st));
+  // conv1d_2 -> relu -> layer_norm_2 -> linear -> mask (-> bucketize + embedding add): the whole tail rides on conv1d_2's
+  // full-row epilogue when that tile applies
+  if (fuse_row_epilogue(M, F, F)) {
+    RowEpilogue e;
+    memset(&e, 0, sizeof(e));
+    e.ln_g = m->P(w.ln2_g); e.ln_b = m->P(w.ln2_b); e.lens = lens; e.wlin = m->P(w.lin_w); e.blin = m->P(w.lin_b); e.pred = pred;
+    e.control = control; e.target = target; e.bins = bins; e.n_edges = c.n_bins - 1; e.emb = emb; e.x_in = x; e.pos = pos; e.x_out = x_out;
+    e.D = w.cin;
+    return gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, nullptr, F, M, F, F, c.vp_kernel, S, ACT_RELU, st, &e, EPI_LN_PRED);
+  }
   NS_TRY(gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st));
   NS_HIP(launch_ln_linear_embed(sc.vp1, m->P(w.ln2_g), m->P(w.ln2_b), m->P(w.lin_w), m->P(w.lin_b), pred, M, F, S, lens,
                                 control, target, bins, c.n_bins, emb, x, pos, x_out, w.cin, st));
@@ -463,8 +526,12 @@ static int postnet(const ns_model* m, const float* mel, int B, int T, const floa
     const PostW& w = m->post[i];
     const bool last = i + 1 == m->post.size();
     float* dst = last ? out : ((i & 1) ? pong : ping);
+    const bool mid = w.cin == c.postnet_dim && w.cout == c.postnet_dim;
+    ProfScope ps(m, 2, st, 2.0 * (double)M * (double)c.postnet_k * (double)w.cin * (double)w.cout);
+    if (mid) NS_TRY(ps.begin());
     NS_TRY(gemm(cur, ld, m->P(w.w), m->P(w.b), last ? resid : nullptr, c.n_mel, dst, w.cout, M, w.cout, w.cin, c.postnet_k, T,
                 last ? ACT_NONE : ACT_TANH, st));
+    if (mid) NS_TRY(ps.end());
     cur = dst;
     ld = w.cout;
   }
@@ -478,7 +545,7 @@ static int encoder(const ns_model* m, const long long* texts, const long long* l
   const float* pos;
   NS_TRY(position_rows(m, m->enc_pos, L, d, sc, &pos, st));
   float* cur = m->enc.empty() ? out : sc.xa;
-  NS_HIP(launch_embed_pos(texts, m->P(m->emb), pos, cur, M, L, d, st));
+  NS_HIP(launch_embed_pos(texts, m->P(m->emb), pos, cur, M, L, d, c.n_vocab, st));
   for (size_t i = 0; i < m->enc.size(); ++i) {
     float* dst = (i + 1 == m->enc.size()) ? out : (cur == sc.xa ? sc.xb : sc.xa);
     NS_TRY(fft_block(m, m->enc[i], d, c.n_enc_head, cur, lens, B, L, dst, sc, st));
@@ -533,7 +600,8 @@ extern "C" int ns_forward_durations(ns_model* m, const int64_t* texts, const int
   }
   // src mask (utils/tools.py:89-97), duration rounding (model/modules.py:132-135), repeat counts + prefix sums + mel_len
   // (:209-223): one launch
-  NS_HIP(launch_duration_tail(log_d, lens, B, L, d_control, d_rounded, dur_keep, cum, (long long*)mel_lens, src_mask, st));
+  NS_HIP(launch_duration_tail(log_d, lens, (const long long*)texts, c.n_vocab, B, L, d_control, d_rounded, dur_keep, cum,
+                              (long long*)mel_lens, src_mask, st));
   return 0;
 }
 
@@ -587,14 +655,13 @@ extern "C" int ns_forward_mel(ns_model* m, int B, int L, int T, const int64_t* m
     NS_HIP(launch_add_pos(cur, pos, alt, M, T, d, st));
     float* t = cur; cur = alt; alt = t;
   }
-  m->prof_active = m->prof;  // time only the decoder stack's launches: one shape, [B*T, k*d] x [k*d, d_inner]
-  const int rc_dec = decoder_stack(m, cur, lens, B, T, sc.att, sc, st);
-  m->prof_active = false;
-  NS_TRY(rc_dec);
+  m->prof_active = m->prof;  // time only phase 2's launches: one shape per slot (the encoder runs the same kernels at B*L rows)
+  int rc = decoder_stack(m, cur, lens, B, T, sc.att, sc, st);
   // note: decoder_stack's last layer writes into sc.att only after its own attention output was consumed
-  NS_TRY(gemm(sc.att, d, m->P(m->mel_w), m->P(m->mel_b), nullptr, 0, mel, c.n_mel, M, c.n_mel, d, 1, T, ACT_NONE, st));
-  NS_TRY(postnet(m, mel, B, T, mel, postnet_mel, sc, st));
-  return 0;
+  if (!rc) rc = gemm(sc.att, d, m->P(m->mel_w), m->P(m->mel_b), nullptr, 0, mel, c.n_mel, M, c.n_mel, d, 1, T, ACT_NONE, st);
+  if (!rc) rc = postnet(m, mel, B, T, mel, postnet_mel, sc, st);
+  m->prof_active = false;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------- per-op entry points
@@ -693,25 +760,29 @@ extern "C" int ns_op_variance_embedding(ns_model* m, int which, const float* x, 
 extern "C" int ns_profile_enable(ns_model* m, int on) {
   if (!m) return fail("ns_profile_enable: null model");
   m->prof = on != 0;
-  m->prof_used = 0;
-  m->prof_flops = 0.0;
+  for (auto& ps : m->prof_slot) { ps.used = 0; ps.flops = 0.0; }
   return 0;
 }
-extern "C" int ns_profile_read(ns_model* m, double* total_ms, double* total_flops, int64_t* launches) {
-  if (!m) return fail("ns_profile_read: null model");
+extern "C" int ns_profile_read_slot(ns_model* m, int slot, double* total_ms, double* total_flops, int64_t* launches) {
+  if (!m) return fail("ns_profile_read_slot: null model");
+  if (slot < 0 || slot >= NS_PROFILE_SLOTS) return fail("ns_profile_read_slot: slot out of range");
+  ns_model::ProfSlot& ps = m->prof_slot[slot];
   double ms = 0.0;
-  for (size_t i = 0; i < m->prof_used; ++i) {
-    NS_HIP(hipEventSynchronize(m->prof_ev[i].second));
+  for (size_t i = 0; i < ps.used; ++i) {
+    NS_HIP(hipEventSynchronize(ps.ev[i].second));
     float e = 0.f;
-    NS_HIP(hipEventElapsedTime(&e, m->prof_ev[i].first, m->prof_ev[i].second));
+    NS_HIP(hipEventElapsedTime(&e, ps.ev[i].first, ps.ev[i].second));
     ms += e;
   }
   if (total_ms) *total_ms = ms;
-  if (total_flops) *total_flops = m->prof_flops;
-  if (launches) *launches = (int64_t)m->prof_used;
-  m->prof_used = 0;
-  m->prof_flops = 0.0;
+  if (total_flops) *total_flops = ps.flops;
+  if (launches) *launches = (int64_t)ps.used;
+  ps.used = 0;
+  ps.flops = 0.0;
   return 0;
+}
+extern "C" int ns_profile_read(ns_model* m, double* total_ms, double* total_flops, int64_t* launches) {
+  return ns_profile_read_slot(m, 0, total_ms, total_flops, launches);
 }
 extern "C" int ns_op_bucketize(const float* values, int n, const float* bins, int n_edges, int64_t* idx, void* stream) {
   NS_HIP(launch_bucketize(values, n, bins, n_edges, (long long*)idx, (hipStream_t)stream));

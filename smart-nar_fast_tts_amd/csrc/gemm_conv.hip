@@ -30,17 +30,16 @@
 //
 // Operand reads use the freedom to permute k identically on both operands: lane-half h of MFMA step e in
 // group g consumes k = 8g + 4h + e, so each lane reads its 4 steps' operands with ONE ds_read_b128.
-#include "kernels.h"
+#include "rowln.h"
 
 namespace ns {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 [[maybe_unused]] constexpr int OOR = (int)0x80000000;  // voffset marker: beyond num_records -> the DMA writes zeros
 
-template <int BM, int BN, int BK, int KS, int WGM = 2, int WGN = 2>
+template <int BM, int BN, int BK, int KS, int WGM = 2, int WGN = 2, bool ROWEPI = false>
 __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, int ntn) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type does not exist in the host pass; it only needs the stub
   constexpr int NW = WGM * WGN;       // waves per K-split group, arranged WGM x WGN over the block tile
@@ -52,7 +51,10 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
   constexpr int FSH = (BK == 64) ? 0 : (BK == 32) ? 1 : 2;
   constexpr int FMSK = CPR - 1;
   static_assert(BK == 64 || BK == 32 || BK == 16, "BK");
-  static_assert(KS == 1 || (KS - 1) * BM * BN <= 2 * KS * BM * BK, "split-K partial tiles must fit the A staging buffers");
+  // split-K partial tiles (BM*BN floats each) are parked in the two B staging objects, whole tiles per object
+  static_assert(KS == 1 || ((KS * BN * BK) / (BM * BN) >= 1 && (KS - 1) <= 2 * ((KS * BN * BK) / (BM * BN))),
+                "split-K partial tiles must fit the B staging buffers");
+  static_assert(!ROWEPI || (KS == 1 && BM <= 2 * BK && BN % 256 == 0 && BM % (WGM * WGN) == 0), "row epilogue: the BM x BN tile is parked in the two B staging buffers");
 
   // Four DISTINCT LDS objects (not [2][...] arrays) and a 2x unrolled K loop with a static buffer index: hipcc tracks
   // in-flight LDS-DMA per LDS object, so a ds_read from As0 does not wait for a DMA that is filling As1.  With one
@@ -203,12 +205,13 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
   }
 
   if (KS > 1) {
-    // sum the K-split partial tiles: groups 1..KS-1 park their accumulators in the (now idle) A staging buffers,
-    // lane-linear, group 0 adds them in group order and runs the epilogue
+    // sum the K-split partial tiles: groups 1..KS-1 park their accumulators in the (now idle) B staging buffers,
+    // lane-linear, PER_OBJ whole tiles per LDS object (never straddling one); group 0 adds them in group order and runs
+    // the epilogue
     constexpr int TILE = BM * BN;
-    constexpr int PER_OBJ = (KS * BM * BK) / TILE > 0 ? (KS * BM * BK) / TILE : 1;
+    constexpr int PER_OBJ = (KS * BN * BK) / TILE;
     if (grp > 0) {
-      float* red = ((grp - 1) / PER_OBJ ? As1 : As0) + ((grp - 1) % PER_OBJ) * TILE;
+      float* red = ((grp - 1) / PER_OBJ ? Bs1 : Bs0) + ((grp - 1) % PER_OBJ) * TILE;
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
     if (grp > 0) return;
 #pragma unroll
     for (int g2 = 1; g2 < KS; ++g2) {
-      const float* red = ((g2 - 1) / PER_OBJ ? As1 : As0) + ((g2 - 1) % PER_OBJ) * TILE;
+      const float* red = ((g2 - 1) / PER_OBJ ? Bs1 : Bs0) + ((g2 - 1) % PER_OBJ) * TILE;
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -232,40 +235,102 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
 
   // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int ecol = lane & 31, erow = (lane >> 5) * 4;
+  if constexpr (ROWEPI) {
+    // Full-row tile (BN == N): park act(acc + bias) as a row-major [BM][BN] tile in the (idle) first B staging buffer,
+    // then every wave takes BM / waves whole rows — one row per wave64, float4 lanes — and runs the row kernel's own
+    // code on them (rowln.h): residual add, LayerNorm, mask / predictor tail, coalesced 1-KB row stores.
+    auto trow = [&](int ml) -> float* { return (ml < BK ? Bs0 : Bs1) + (ml % BK) * BN; };  // rows [0,BK) in Bs0, [BK,2BK) in Bs1
 #pragma unroll
-  for (int ni = 0; ni < TN; ++ni) {
-    const int n = n0 + wn0 + ni * 32 + ecol;
-    if (n >= p.N) continue;
-    const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int ni = 0; ni < TN; ++ni) {
+      const int nl = wn0 + ni * 32 + ecol;
+      const float bv = p.bias ? p.bias[n0 + nl] : 0.f;
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
+      for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + erow;
-        if (m >= p.M) continue;
-        float v = acc[mi][ni][r] + bv;
-        if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
-        else if (p.act == ACT_TANH) v = tanhf(v);
-        if (p.resid) v += p.resid[(size_t)m * p.ldr + n];
-        p.Y[(size_t)m * p.ldy + n] = v;
+        for (int r = 0; r < 16; ++r) {
+          const int ml = wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + erow;
+          float v = acc[mi][ni][r] + bv;
+          if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
+          else if (p.act == ACT_TANH) v = tanhf(v);
+          trow(ml)[nl] = v;
+        }
+      }
+    }
+    __syncthreads();
+    constexpr int NV = BN / 256, RPW = BM / NW;
+#pragma unroll 1
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int ml = wid * RPW + rr, m = m0 + ml;
+      if (m >= p.M) break;
+      const int b = m / p.S, t = m - b * p.S;
+      const bool masked = p.e.lens && (long long)t >= p.e.lens[b];
+      if (p.epi == EPI_LN && masked) {  // masked_fill(mask, 0): a padded row is written, never computed
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + lane * 4 + i * 256) = f32x4{0.f, 0.f, 0.f, 0.f};
+        continue;
+      }
+      f32x4 v[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(trow(ml) + lane * 4 + i * 256);
+        if (p.resid) v[i] += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + lane * 4 + i * 256);
+      }
+      float mean, rstd;
+      ln_moments<NV>(v, BN, lane, mean, rstd);
+      if (p.epi == EPI_LN) ln_store<NV>(v, BN, lane, mean, rstd, p.e.ln_g, p.e.ln_b, p.Y + (size_t)m * p.ldy);
+      else predictor_row_tail<NV>(v, BN, lane, mean, rstd, p.e, m, t, masked);
+    }
+  } else {
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int n = n0 + wn0 + ni * 32 + ecol;
+      if (n >= p.N) continue;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + erow;
+          if (m >= p.M) continue;
+          float v = acc[mi][ni][r] + bv;
+          if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
+          else if (p.act == ACT_TANH) v = tanhf(v);
+          if (p.resid) v += p.resid[(size_t)m * p.ldr + n];
+          p.Y[(size_t)m * p.ldy + n] = v;
+        }
       }
     }
   }
 #endif
 }
 
-template <int BM, int BN, int BK, int KS = 1, int WGM = 2, int WGN = 2>
+template <int BM, int BN, int BK, int KS = 1, int WGM = 2, int WGN = 2, bool ROWEPI = false>
 static hipError_t launch_t(const ConvGemm& p, hipStream_t st) {
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, p, ntn);
+  hipLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN, ROWEPI>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, p, ntn);
   return hipGetLastError();
+}
+
+bool conv_gemm_row_epilogue_ok(int M, int N, int Cin) {
+  return M > 0 && (N == 256 || N == 512) && Cin % 32 == 0;
 }
 
 hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if (p.Cin % 16 != 0 || (p.ldx & 3) != 0) return hipErrorInvalidValue;
   // descriptor offsets are 31-bit: a tile's rows (BM + KW) * ldx and BN * K floats must stay below 2^29 floats
-  if ((long long)(128 + p.KW) * p.ldx >= (1ll << 29) || (long long)128 * p.KW * p.Cin >= (1ll << 29)) return hipErrorInvalidValue;
+  if ((long long)(128 + p.KW) * p.ldx >= (1ll << 29) || (long long)512 * p.KW * p.Cin >= (1ll << 29)) return hipErrorInvalidValue;
+  if (p.epi != EPI_NONE) {
+    // full-row tile: 32 rows x N columns, N / 32 waves side by side with one 32x32 MFMA tile each
+    if (!conv_gemm_row_epilogue_ok(p.M, p.N, p.Cin) || (p.ldy & 3) || (p.resid && (p.ldr & 3))) return hipErrorInvalidValue;
+#if defined(NS_LAB_ROW64)
+    if (p.N == 256) return launch_t<64, 256, 32, 1, 2, 4, true>(p, st);
+#elif defined(NS_LAB_ROW64W16)
+    if (p.N == 256) return launch_t<64, 256, 32, 1, 2, 8, true>(p, st);
+#endif
+    if (p.N == 256) return launch_t<32, 256, 32, 1, 1, 8, true>(p, st);
+    return launch_t<32, 512, 32, 1, 1, 16, true>(p, st);
+  }
   const bool bk32 = (p.Cin % 32) == 0;
   // Tile / wave-grid choice (tools/lab sweeps on the path's shapes, MI355X, same-run comparisons).  What wins is
   // many waves per workgroup with ONE 32x32 MFMA tile each: 8 waves as 2x4 over a 64x256 or 64x128 block tile.  The

@@ -7,6 +7,23 @@ namespace ns {
 
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 
+// Row epilogue of a FULL-ROW tile (N == the tile width, 256 or 512): what the reference applies to every output row right
+// after the contraction, done while the row is still on chip instead of by a second kernel over [M, N].
+//   EPI_LN      Y[m,:] = LayerNorm_N(v[m,:]) * ln_g + ln_b, rows at t >= lens[b] written as zeros when lens != nullptr
+//               (`layer_norm(output + residual)` + FFTBlock's masked_fill, transformer/SubLayers.py:57,93 + Layers.py:43,46;
+//               the predictors' layer_norm_1, model/modules.py:260)
+//   EPI_LN_PRED pred[m] = mask ? 0 : dot(LayerNorm_N(v[m,:]), wlin) + blin, optionally followed by the bucketize +
+//               embedding (+ position) add into x_out [M, D] (VariancePredictor tail, model/modules.py:273-286,80-100,139-149);
+//               Y is not written
+// v = act(contraction + bias) + resid, exactly what the plain epilogue would have stored.
+enum RowEpi : int { EPI_NONE = 0, EPI_LN = 1, EPI_LN_PRED = 2 };
+struct RowEpilogue {
+  const float* ln_g; const float* ln_b;
+  const long long* lens;
+  const float* wlin; const float* blin; float* pred; float control; const float* target;
+  const float* bins; int n_edges; const float* emb; const float* x_in; const float* pos; float* x_out; int D;
+};
+
 // Y[m, n] = act( sum_{j<KW} sum_{c<Cin} X[m + j - pad, c] * W[n][j*Cin + c] + bias[n] ) + resid[m, n]
 // rows of X outside the utterance's [0, S) window read as zero ("same" zero padding of nn.Conv1d).
 struct ConvGemm {
@@ -17,8 +34,13 @@ struct ConvGemm {
   float* Y; int ldy;
   int M, N, Cin, KW, pad, S;
   int act;
+  int epi;                      // RowEpi; != EPI_NONE requires conv_gemm_row_epilogue_ok(p)
+  RowEpilogue e;
 };
 hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st);
+// true when launch_conv_gemm has a full-row tile for this shape (so p.epi may be set); otherwise the caller runs the
+// plain GEMM followed by the row kernel
+bool conv_gemm_row_epilogue_ok(int M, int N, int Cin);
 
 // Fused multi-head self attention over the packed projection buffer qkv [B*S, 3*d]
 // (cols [0,d) = Q, [d,2d) = K, [2d,3d) = V, head h at offset h*dk inside each).
@@ -40,7 +62,9 @@ hipError_t launch_ln_linear_embed(const float* x, const float* g, const float* b
                                   const float* target, const float* bins, int n_bins, const float* emb, const float* x_in, const float* pos,
                                   float* x_out, int D, hipStream_t st);
 // out[m,:] = emb[texts[m],:] + pos[t,:]
-hipError_t launch_embed_pos(const long long* texts, const float* emb, const float* pos, float* out, int M, int S, int D, hipStream_t st);
+// token ids outside [0, n_vocab) read row 0 (and are reported by launch_duration_tail)
+hipError_t launch_embed_pos(const long long* texts, const float* emb, const float* pos, float* out, int M, int S, int D, int n_vocab,
+                            hipStream_t st);
 hipError_t launch_add_pos(const float* x, const float* pos, float* out, int M, int S, int D, hipStream_t st);
 hipError_t launch_bucketize(const float* v, int n, const float* bins, int n_edges, long long* idx, hipStream_t st);
 hipError_t launch_mask_from_lengths(const long long* lens, int B, int max_len, uint8_t* mask, hipStream_t st);
@@ -50,9 +74,11 @@ hipError_t launch_duration_scan(const float* d_rounded, int B, int L, int32_t* c
 // mel_mask (nullable): also writes get_mask_from_lengths(mel_len) for the [B,T] frame grid
 hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int L, int D, int T, float* out, uint8_t* mel_mask,
                                   hipStream_t st);
-// phase-1 tail in one launch: src mask, duration_round (two copies), duration_scan
-hipError_t launch_duration_tail(const float* log_d, const long long* src_lens, int B, int L, float d_control, float* d_rounded,
-                                float* d_keep, int32_t* cum, long long* mel_lens, uint8_t* src_mask, hipStream_t st);
+// phase-1 tail in one launch: src mask, duration_round (two copies), duration_scan; mel_lens[b] = -1 when utterance b
+// holds a token id outside [0, n_vocab) (texts may be nullptr: no check)
+hipError_t launch_duration_tail(const float* log_d, const long long* src_lens, const long long* texts, int n_vocab, int B, int L,
+                                float d_control, float* d_rounded, float* d_keep, int32_t* cum, long long* mel_lens, uint8_t* src_mask,
+                                hipStream_t st);
 hipError_t launch_gaussian_upsampling(const float* x, const float* dur, int B, int L, int D, int T, int T_out,
                                       float* out, float* s, float* w, const long long* own_len, hipStream_t st);
 

@@ -1,55 +1,19 @@
 // Row-wise (HBM-bound) kernels of the path: one wave64 per activation row, float4 (16 B/lane) accesses,
 // wavefront shuffles for the reductions.  Each one cites the reference lines it restates.
-#include "kernels.h"
+#include "rowln.h"
 
 namespace ns {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-constexpr float LN_EPS = 1e-5f;  // torch.nn.LayerNorm default
-
-// torch.bucketize(v, bins, right=False) (model/modules.py:86-88,97-99), wave-cooperative: the index is the number
-// of edges e with !(e >= v) — for sorted edges that is the first i with bins[i] >= v, and NaN maps to n_edges.
-__device__ __forceinline__ int wave_bucketize(const float* __restrict__ bins, int n_edges, float v, int lane) {
-  int cnt = 0;
-  for (int k = lane; k < n_edges; k += 64) cnt += !(bins[k] >= v) ? 1 : 0;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-  return cnt;
-}
 
 // Loads row `x` (C floats, C % 4 == 0, C <= 1024) as up to NV float4 per lane and returns mean / rstd.
 template <int NV>
 __device__ __forceinline__ void ln_stats(const float* x, int C, int lane, f32x4 (&v)[NV], float& mean, float& rstd) {
-  float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + i * 256;
     if (c < C) v[i] = *reinterpret_cast<const f32x4*>(x + c);
     else v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   }
-  mean = wave_sum(s) / (float)C;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = lane * 4 + i * 256;
-    if (c < C) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float dlt = v[i][e] - mean;
-        q += dlt * dlt;
-      }
-    }
-  }
-  const float var = wave_sum(q) / (float)C;  // biased variance, as nn.LayerNorm
-  rstd = 1.0f / sqrtf(var + LN_EPS);
+  ln_moments<NV>(v, C, lane, mean, rstd);
 }
 
 // y = LN(x)*g + b ; rows at t >= lens[b] -> 0.  Covers `layer_norm(output + residual)` followed by
@@ -69,18 +33,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
   f32x4 v[NV];
   float mean, rstd;
   ln_stats<NV>(x + (size_t)m * C, C, lane, v, mean, rstd);
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = lane * 4 + i * 256;
-    if (c < C) {
-      const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c);
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(bta + c);
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
-      *reinterpret_cast<f32x4*>(y + (size_t)m * C + c) = o;
-    }
-  }
+  ln_store<NV>(v, C, lane, mean, rstd, g, bta, y + (size_t)m * C);
 }
 
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, int C, int S,
@@ -114,35 +67,11 @@ __global__ __launch_bounds__(256) void k_ln_linear_embed(const float* __restrict
   f32x4 v[NV];
   float mean, rstd;
   ln_stats<NV>(x + (size_t)m * C, C, lane, v, mean, rstd);
-  float dot = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = lane * 4 + i * 256;
-    if (c < C) {
-      const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c);
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(bta + c);
-      const f32x4 ww = *reinterpret_cast<const f32x4*>(wlin + c);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dot += ((v[i][e] - mean) * rstd * gg[e] + bb[e]) * ww[e];
-    }
-  }
+  RowEpilogue e;
+  e.ln_g = g; e.ln_b = bta; e.lens = lens; e.wlin = wlin; e.blin = blin; e.pred = pred; e.control = control; e.target = target;
+  e.bins = bins; e.n_edges = n_edges; e.emb = emb; e.x_in = x_in; e.pos = pos; e.x_out = x_out; e.D = D;
   const int t = m % S;
-  float pv = wave_sum(dot) + blin[0];
-  if (lens && (long long)t >= lens[m / S]) pv = 0.f;
-  // model/modules.py:82-89: with a target the embedding comes from bucketize(target) and the prediction is returned
-  // unscaled; without one prediction = prediction * control and the embedding comes from the scaled prediction
-  if (target == nullptr) pv *= control;
-  if (lane == 0) pred[m] = pv;
-  if (emb == nullptr) return;
-  const int cnt = wave_bucketize(bins, n_edges, target ? target[m] : pv, lane);
-  const float* er = emb + (size_t)cnt * D;
-  for (int c = lane * 4; c < D; c += 256) {
-    f32x4 a = *reinterpret_cast<const f32x4*>(x_in + (size_t)m * D + c);
-    const f32x4 e4 = *reinterpret_cast<const f32x4*>(er + c);
-    a += e4;
-    if (pos) a += *reinterpret_cast<const f32x4*>(pos + (size_t)t * D + c);
-    *reinterpret_cast<f32x4*>(x_out + (size_t)m * D + c) = a;
-  }
+  predictor_row_tail<NV>(v, C, lane, mean, rstd, e, m, t, lens && (long long)t >= lens[m / S]);
 }
 
 hipError_t launch_ln_linear_embed(const float* x, const float* g, const float* b, const float* wlin, const float* blin,
@@ -176,12 +105,15 @@ hipError_t launch_bucketize(const float* v, int n, const float* bins, int n_edge
 }
 
 // TxtEncoder.forward input: src_word_emb(src_seq) + position_enc[:, :L] (transformer/Models.py:82-91).
+// A token id outside [0, n_vocab) (nn.Embedding raises IndexError) reads row 0 here and is reported by the duration tail.
 __global__ __launch_bounds__(256) void k_embed_pos(const long long* __restrict__ texts, const float* __restrict__ emb,
-                                                    const float* __restrict__ pos, float* __restrict__ out, int M, int S, int D) {
+                                                    const float* __restrict__ pos, float* __restrict__ out, int M, int S, int D,
+                                                    int n_vocab) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
-  const long long tok = texts[m];
+  long long tok = texts[m];
+  if (tok < 0 || tok >= (long long)n_vocab) tok = 0;
   const int t = m % S;
   for (int c = lane * 4; c < D; c += 256) {
     f32x4 a = *reinterpret_cast<const f32x4*>(emb + (size_t)tok * D + c);
@@ -189,9 +121,10 @@ __global__ __launch_bounds__(256) void k_embed_pos(const long long* __restrict__
     *reinterpret_cast<f32x4*>(out + (size_t)m * D + c) = a;
   }
 }
-hipError_t launch_embed_pos(const long long* texts, const float* emb, const float* pos, float* out, int M, int S, int D, hipStream_t st) {
+hipError_t launch_embed_pos(const long long* texts, const float* emb, const float* pos, float* out, int M, int S, int D, int n_vocab,
+                            hipStream_t st) {
   if (M <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_embed_pos, dim3((M + 3) / 4), dim3(256), 0, st, texts, emb, pos, out, M, S, D);
+  hipLaunchKernelGGL(k_embed_pos, dim3((M + 3) / 4), dim3(256), 0, st, texts, emb, pos, out, M, S, D, n_vocab);
   return hipGetLastError();
 }
 
@@ -246,11 +179,14 @@ hipError_t launch_sinusoid(int n_pos, int d, float* out, hipStream_t st) {
 
 // duration_rounded = clamp(round(exp(log_d) - 1) * d_control, min=0) (model/modules.py:132-135).
 // torch.round is round-half-to-even -> rintf; the clamp keeps -0.0 and NaN like torch.clamp does.
+__device__ __forceinline__ float duration_round(float log_d, float d_control) {
+  const float r = rintf(expf(log_d) - 1.0f) * d_control;
+  return (r < 0.f) ? 0.f : r;
+}
 __global__ void k_duration_round(const float* __restrict__ log_d, int n, float d_control, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float r = rintf(expf(log_d[i]) - 1.0f) * d_control;
-  out[i] = (r < 0.f) ? 0.f : r;
+  out[i] = duration_round(log_d[i], d_control);
 }
 hipError_t launch_duration_round(const float* log_d, int n, float d_control, float* d_rounded, hipStream_t st) {
   if (n <= 0) return hipSuccess;
@@ -258,68 +194,45 @@ hipError_t launch_duration_round(const float* log_d, int n, float d_control, flo
   return hipGetLastError();
 }
 
-// LengthRegulator.expand's repeat counts (model/modules.py:221-223): max(int(d), 0), int() truncating toward
-// zero, and their inclusive prefix sums; mel_len[b] = total (model/modules.py:209-211).  One workgroup per utterance.
-__global__ __launch_bounds__(256) void k_duration_scan(const float* __restrict__ d, int L, int32_t* __restrict__ cum,
-                                                        long long* __restrict__ mel_lens) {
+// One body, two instantiations.  One workgroup per utterance walks its L phonemes 256 at a time:
+//   TAIL = false  (ns_op_duration_scan): LengthRegulator.expand's repeat counts (model/modules.py:221-223), max(int(d), 0)
+//                 with int() truncating toward zero, their inclusive prefix sums, mel_len[b] = total (:209-211);
+//   TAIL = true   (the forward's phase-1 tail, ONE launch): additionally produces its own input — the rounded durations
+//                 from log_d (two copies: the caller's output and the workspace copy phase 2 reads) — and the source
+//                 mask (utils/tools.py:89-97), and reports a token id outside [0, n_vocab) as mel_len[b] = -1
+//                 (nn.Embedding raises IndexError there; the host raises it after its one read of mel_lens).
+template <bool TAIL>
+__global__ __launch_bounds__(256) void k_duration_scan(const float* __restrict__ in, int L, int32_t* __restrict__ cum,
+                                                        long long* __restrict__ mel_lens, const long long* __restrict__ src_lens,
+                                                        float d_control, float* __restrict__ d_rounded, float* __restrict__ d_keep,
+                                                        uint8_t* __restrict__ src_mask, const long long* __restrict__ texts,
+                                                        int n_vocab) {
   __shared__ int wsum[4];
   __shared__ int carry_s;
+  __shared__ int bad_s;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int l0 = 0; l0 < L; l0 += 256) {
-    const int l = l0 + tid;
-    int v = 0;
-    if (l < L) {
-      const int r = (int)d[(size_t)b * L + l];
-      v = r > 0 ? r : 0;
-    }
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int n = __shfl_up(inc, o);
-      if (lane >= o) inc += n;
-    }
-    if (lane == 63) wsum[wid] = inc;
-    __syncthreads();
-    int off = carry_s;
-    for (int w = 0; w < wid; ++w) off += wsum[w];
-    if (l < L) cum[(size_t)b * L + l] = inc + off;
-    __syncthreads();
-    if (tid == 255) carry_s = inc + off;
-    __syncthreads();
-  }
-  if (tid == 0) mel_lens[b] = (long long)carry_s;
-}
-hipError_t launch_duration_scan(const float* d_rounded, int B, int L, int32_t* cum, long long* mel_lens, hipStream_t st) {
-  if (B <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_duration_scan, dim3(B), dim3(256), 0, st, d_rounded, L, cum, mel_lens);
-  return hipGetLastError();
-}
-
-// The whole duration tail of phase 1 in ONE launch (what the four kernels above do one after the other; the forward
-// uses this, the per-op entry points keep the separate kernels): src mask, rounded durations (two copies: the caller's
-// output and the workspace copy phase 2 reads), truncated repeat counts, their prefix sums, mel_len.
-__global__ __launch_bounds__(256) void k_duration_tail(const float* __restrict__ log_d, const long long* __restrict__ src_lens,
-                                                        int L, float d_control, float* __restrict__ d_rounded,
-                                                        float* __restrict__ d_keep, int32_t* __restrict__ cum,
-                                                        long long* __restrict__ mel_lens, uint8_t* __restrict__ src_mask) {
-  __shared__ int wsum[4];
-  __shared__ int carry_s;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const long long len = src_lens[b];
-  if (tid == 0) carry_s = 0;
+  long long len = 0;
+  if constexpr (TAIL) len = src_lens[b];
+  if (tid == 0) { carry_s = 0; bad_s = 0; }
   __syncthreads();
   for (int l0 = 0; l0 < L; l0 += 256) {
     const int l = l0 + tid;
     int v = 0;
     if (l < L) {
       const size_t i = (size_t)b * L + l;
-      const float r = rintf(expf(log_d[i]) - 1.0f) * d_control;
-      const float dr = (r < 0.f) ? 0.f : r;
-      d_rounded[i] = dr;
-      d_keep[i] = dr;
-      src_mask[i] = (long long)l >= len ? 1 : 0;
+      float dr;
+      if constexpr (TAIL) {
+        dr = duration_round(in[i], d_control);
+        d_rounded[i] = dr;
+        d_keep[i] = dr;
+        src_mask[i] = (long long)l >= len ? 1 : 0;
+        if (texts) {
+          const long long tok = texts[i];
+          if (tok < 0 || tok >= (long long)n_vocab) bad_s = 1;  // benign race: every writer stores 1
+        }
+      } else {
+        dr = in[i];
+      }
       const int ri = (int)dr;
       v = ri > 0 ? ri : 0;
     }
@@ -338,13 +251,20 @@ __global__ __launch_bounds__(256) void k_duration_tail(const float* __restrict__
     if (tid == 255) carry_s = inc + off;
     __syncthreads();
   }
-  if (tid == 0) mel_lens[b] = (long long)carry_s;
+  if (tid == 0) mel_lens[b] = bad_s ? -1ll : (long long)carry_s;
 }
-hipError_t launch_duration_tail(const float* log_d, const long long* src_lens, int B, int L, float d_control, float* d_rounded,
-                                float* d_keep, int32_t* cum, long long* mel_lens, uint8_t* src_mask, hipStream_t st) {
+hipError_t launch_duration_scan(const float* d_rounded, int B, int L, int32_t* cum, long long* mel_lens, hipStream_t st) {
   if (B <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_duration_tail, dim3(B), dim3(256), 0, st, log_d, src_lens, L, d_control, d_rounded, d_keep, cum, mel_lens,
-                     src_mask);
+  hipLaunchKernelGGL((k_duration_scan<false>), dim3(B), dim3(256), 0, st, d_rounded, L, cum, mel_lens, nullptr, 1.0f, nullptr, nullptr,
+                     nullptr, nullptr, 0);
+  return hipGetLastError();
+}
+hipError_t launch_duration_tail(const float* log_d, const long long* src_lens, const long long* texts, int n_vocab, int B, int L,
+                                float d_control, float* d_rounded, float* d_keep, int32_t* cum, long long* mel_lens, uint8_t* src_mask,
+                                hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL((k_duration_scan<true>), dim3(B), dim3(256), 0, st, log_d, L, cum, mel_lens, src_lens, d_control, d_rounded, d_keep,
+                     src_mask, texts, n_vocab);
   return hipGetLastError();
 }
 

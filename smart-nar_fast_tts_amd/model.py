@@ -58,18 +58,19 @@ class FastSpeech2Align:
         self._h = h
         self._device = None
         self._arena = None
-        self._ws = {}
+        self._ws = OrderedDict()  # (kind, stream handle) -> scratch tensor, least recently used first
         self._sd = OrderedDict()  # host copy of what load_state_dict received (for state_dict() / .to())
+        self._loaded = False      # a full inference state dict was accepted (load_state_dict) ...
+        self._adopted = False     # ... or the packed arena arrived as bytes (adopt_arena)
         self.training = False
-        # VarianceAdaptor.__init__ opens stats.json for the bin edges (model/modules.py:41-71); they are
-        # also state-dict entries, so a checkpoint overrides them.
+        # VarianceAdaptor.__init__ opens stats.json for the bin edges (model/modules.py:41-71).  They are also
+        # state-dict entries, so a checkpoint overrides them; until one is loaded they are only DEFAULTS (kept apart
+        # from _sd: two of ~150 keys are not an uploadable state dict).
+        self._stats = None
         sp = os.path.join(preprocess_config["path"]["preprocessed_path"], "stats.json")
         if os.path.exists(sp):
             with open(sp) as f:
-                stats = json.load(f)
-            pb, eb = wl.variance_bins(model_config, stats)
-            self._sd["variance_adaptor.pitch_bins"] = pb
-            self._sd["variance_adaptor.energy_bins"] = eb
+                self._stats = json.load(f)
 
     def __del__(self):
         try:
@@ -99,11 +100,20 @@ class FastSpeech2Align:
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         if self._device != device:
+            old_arena = self._arena
             self._device = device
+            self._ws = OrderedDict()
             self._arena = None
-            self._ws = {}
-            if self._sd:
-                self._upload()
+            if old_arena is not None or self._loaded:
+                # the native handle must never keep pointing at the old device's arena: rebind first (this also marks
+                # the handle not-ready), then restore the weights on the new device
+                self._bind_arena()
+                if self._loaded:
+                    self._upload()
+                elif self._adopted:  # weights arrived as packed bytes (no host copy): move the bytes, adopt again
+                    self._arena.copy_(old_arena)
+                    torch.cuda.synchronize(device)
+                    self.adopt_arena()
         return self
 
     def cuda(self, device=None):
@@ -112,18 +122,36 @@ class FastSpeech2Align:
     def state_dict(self):
         return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in self._sd.items())
 
+    def _stage(self, key: str, a: np.ndarray):
+        """Hand one entry to the native staging area; it validates the key name and the shape (raises on mismatch)."""
+        shape = (C.c_int64 * a.ndim)(*a.shape)
+        _lib.check(self._lib.ns_set_weight(self._h, key.encode(), C.c_void_p(a.ctypes.data), shape, a.ndim),
+                   "load_state_dict")
+
     def load_state_dict(self, state_dict, strict: bool = True):
         """Accepts the reference's checkpoint["model"] (utils/model.py:21-22).  ``mel_encoder.*`` (training-only
-        aligner) and ``num_batches_tracked`` entries are accepted and ignored."""
+        aligner) and ``num_batches_tracked`` entries are accepted and ignored.  An unexpected key or a shape mismatch
+        raises and leaves the previously loaded weights untouched."""
+        new = OrderedDict()
+        if self._stats is not None and not self._loaded:
+            pb, eb = wl.variance_bins(self.model_config, self._stats)
+            new["variance_adaptor.pitch_bins"] = pb
+            new["variance_adaptor.energy_bins"] = eb
         for k, v in state_dict.items():
-            a = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
             if k.startswith("mel_encoder.") or k.endswith("num_batches_tracked"):
                 continue
-            self._sd[k] = np.ascontiguousarray(a, dtype=np.float32)
+            a = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+            new[k] = np.ascontiguousarray(a, dtype=np.float32)
+        merged = OrderedDict(self._sd)
+        merged.update(new)
+        for k, a in merged.items():  # validated by the native side BEFORE anything is kept
+            self._stage(k, a)
+        self._sd = merged
+        self._loaded, self._adopted = True, False
         if self._device is None and torch.cuda.is_available():
             self._device = torch.device("cuda", torch.cuda.current_device())
         if self._device is not None:
-            self._upload()
+            self._upload(staged=True)
         return [], []
 
     def _bind_arena(self):
@@ -132,15 +160,26 @@ class FastSpeech2Align:
             self._arena = torch.empty(nbytes, dtype=torch.uint8, device=self._device)
             _lib.check(self._lib.ns_bind_arena(self._h, _lib.ptr(self._arena), nbytes), "ns_bind_arena")
 
-    def _upload(self):
+    def _upload(self, staged: bool = False):
         if self._arena is None:
             self._bind_arena()
         with torch.cuda.device(self._device):
-            for k, a in self._sd.items():
-                shape = (C.c_int64 * a.ndim)(*a.shape)
-                _lib.check(self._lib.ns_set_weight(self._h, k.encode(), C.c_void_p(a.ctypes.data), shape, a.ndim),
-                           "load_state_dict")
+            if not staged:
+                for k, a in self._sd.items():
+                    self._stage(k, a)
             _lib.check(self._lib.ns_finalize_weights(self._h, _lib.stream_ptr(self._device)), "load_state_dict")
+
+    def _ensure_weights(self):
+        """The reference constructor leaves a runnable random-init module (model/fastspeech2_align.py:16-28); here the
+        equivalent weights are drawn on first use when nothing was loaded (torch's default initialisers under torch's
+        global RNG, bins from stats.json)."""
+        if self._loaded or self._adopted:
+            return
+        if self._stats is None:
+            raise RuntimeError(
+                "weights not loaded: call load_state_dict() (or provide <preprocessed_path>/stats.json for a "
+                "random-init model like the reference constructor's, model/modules.py:41-46)")
+        self.load_state_dict(wl.default_init_state_dict(self.model_config, self._stats))
 
     # ---- multi-GPU weight replication (SURVEY.md §8e): rank 0 packs, everyone else adopts the bytes ----
     def arena_tensor(self) -> torch.Tensor:
@@ -152,27 +191,44 @@ class FastSpeech2Align:
 
     def adopt_arena(self):
         _lib.check(self._lib.ns_adopt_arena(self._h), "ns_adopt_arena")
+        if not self._loaded:
+            self._adopted = True
 
     # ---- measurement hook (bench.py roofline leg) ----------------------------------------------------
     def profile_dominant_kernel(self, on: bool = True):
         _lib.check(self._lib.ns_profile_enable(self._h, int(on)), "ns_profile_enable")
 
-    def read_profile(self):
-        """(total kernel ms, total algorithmic flops, launches) of the FFN k=9 Conv1D-as-GEMM since the last read."""
+    PROFILE_SLOTS = ("ffn_w1", "attention", "postnet_mid")  # include/nar_fs2.h: slots of ns_profile_read_slot
+
+    def read_profile(self, slot: int = 0):
+        """(total kernel ms, total algorithmic flops, launches) of one profiled launch group since the last read;
+        slot 0 = the FFN k=9 Conv1D-as-GEMM (the dominant kernel), 1 = fused attention, 2 = PostNet 512->512 k=5."""
         ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
-        _lib.check(self._lib.ns_profile_read(self._h, C.byref(ms), C.byref(fl), C.byref(n)), "ns_profile_read")
+        _lib.check(self._lib.ns_profile_read_slot(self._h, int(slot), C.byref(ms), C.byref(fl), C.byref(n)),
+                   "ns_profile_read_slot")
         return ms.value, fl.value, n.value
 
     # ---- forward -------------------------------------------------------------------------------
+    MAX_WORKSPACE_STREAMS = 4  # scratch sets kept alive (each is an enc + dec pair; config 2: ~230 MB per stream)
+
     def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
         # one scratch set per (kind, stream): forwards issued on different streams may run concurrently on the GPU
-        # (batching.synthesize pipelines consecutive batches that way) and must not share temporaries
+        # (batching.synthesize pipelines consecutive batches that way) and must not share temporaries.  The cache is
+        # LRU-bounded: every synthesize(streams=N) call makes fresh streams, and a dropped set goes back to torch's
+        # caching allocator, which only re-issues it in stream order.
         key = (key, torch.cuda.current_stream(self._device).cuda_stream)
         w = self._ws.get(key)
         if w is None or w.numel() < nbytes:
             w = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self._device)
             self._ws[key] = w
+        self._ws.move_to_end(key)
+        while len(self._ws) > 2 * self.MAX_WORKSPACE_STREAMS:
+            self._ws.popitem(last=False)
         return w
+
+    def release_workspaces(self):
+        """Drop every cached scratch set (they are re-created on demand)."""
+        self._ws = OrderedDict()
 
     def __call__(self, *args, **kwargs):
         return self.forward(*args, **kwargs)
@@ -194,6 +250,7 @@ class FastSpeech2Align:
             raise RuntimeError("inputs must live on the MI355X (cuda) device; there is no CPU path")
         if self._device != texts.device:
             self.to(texts.device)
+        self._ensure_weights()
         lib, dev = self._lib, self._device
         B, L = int(texts.shape[0]), int(texts.shape[1])
         if int(max_src_len) != L:
@@ -230,10 +287,15 @@ class FastSpeech2Align:
                 _lib.ptr(out_mel_lens), _lib.ptr(p_pred), _lib.ptr(e_pred), st), "ns_forward_durations")
             # the one device->host read: output shapes depend on max(mel_len)
             # (the reference syncs here too: utils/tools.py:92, plus B*L .item() calls at model/modules.py:222)
+            # (a token id outside [0, n_vocab) comes back as mel_len = -1 for its utterance; nn.Embedding raises IndexError)
+            ml_host = out_mel_lens.cpu()  # one small D2H copy, [B] int64
+            if int(ml_host.min()) < 0:
+                bad = [i for i, v in enumerate(ml_host.tolist()) if v < 0]
+                raise IndexError(f"index out of range in self: token id outside [0, {self._cfg.n_vocab}) in utterance(s) {bad}")
             if callable(max_mel_len):
-                T = int(max_mel_len(out_mel_lens.max()))
+                T = int(max_mel_len(ml_host.max().to(dev)))
             else:
-                T = int(out_mel_lens.cpu().max()) if B <= 4096 else int(out_mel_lens.max().item())  # one small D2H copy
+                T = int(ml_host.max())
                 if max_mel_len is not None:
                     if int(max_mel_len) < T:
                         raise ValueError(f"max_mel_len ({int(max_mel_len)}) is smaller than the longest utterance ({T})")

@@ -226,6 +226,40 @@ def synth_state_dict(model_cfg: dict, seed: int = 0, frames_per_phoneme: float =
     return sd
 
 
+def default_init_state_dict(model_cfg: dict, stats: dict) -> "OrderedDict[str, np.ndarray]":
+    """What the reference constructor leaves in the module (model/fastspeech2_align.py:16-28): every layer is a stock
+    ``torch.nn`` module with torch's default initialiser — Linear / Conv1d ``kaiming_uniform_(a=sqrt(5))`` = U(+-1/sqrt(fan_in))
+    for weight and bias, Embedding N(0,1) with the padding row zeroed, LayerNorm / BatchNorm affine (1, 0), running stats
+    (0, 1) — drawn here from torch's GLOBAL generator so that ``torch.manual_seed`` controls it as it does there (the draw
+    order differs from the reference's module construction order, so the values are equivalent in distribution, not
+    equal).  Bins come from ``stats.json`` (model/modules.py:41-71).  Inference subset only (no ``mel_encoder``)."""
+    import torch
+
+    sd = synth_state_dict(model_cfg, seed=0, stats=stats)  # key set and shapes; every value is overwritten below
+    pb, eb = variance_bins(model_cfg, stats)
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for k, v in sd.items():
+        if k.endswith("position_enc") or k.endswith("num_batches_tracked"):
+            out[k] = v
+        elif k.endswith("pitch_bins"):
+            out[k] = pb
+        elif k.endswith("energy_bins"):
+            out[k] = eb
+        elif "layer_norm" in k or ".1." in k and k.startswith("postnet."):  # LayerNorm / BatchNorm1d
+            one = k.endswith(".weight") or k.endswith("running_var")
+            out[k] = np.full(v.shape, 1.0 if one else 0.0, dtype=np.float32)
+        elif k.endswith("embedding.weight") or k.endswith("src_word_emb.weight"):
+            e = torch.randn(*v.shape).numpy()
+            if k.endswith("src_word_emb.weight"):
+                e[0] = 0.0  # padding_idx
+            out[k] = e
+        else:  # Linear [out, in] / Conv1d [out, in, k] weight, or their bias [out] (fan_in from the matching weight)
+            w = sd[k[:-len(".bias")] + ".weight"] if k.endswith(".bias") else v
+            bound = 1.0 / math.sqrt(int(np.prod(w.shape[1:])))
+            out[k] = torch.empty(*v.shape).uniform_(-bound, bound).numpy()
+    return out
+
+
 def synth_inputs(batch: int, max_src_len: int, seed: int = 0, src_lens=None):
     """texts ~ randint(1, 361) zero-padded, src_lens (default all = L), speakers = 0."""
     rs = np.random.RandomState(seed + 1000003)

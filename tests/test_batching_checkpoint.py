@@ -121,3 +121,91 @@ def test_stream_pipelined_synthesize_is_identical():
         for a, b in zip(one, many):
             assert a["mel_len"] == b["mel_len"] and torch.equal(a["mel"], b["mel"]), a["basename"]
             assert np.array_equal(a["pitch"], b["pitch"]) and np.array_equal(a["duration"], b["duration"])
+
+
+@pytest.mark.gpu
+def test_get_model_flow_with_stats_json(tmp_path):
+    """utils/model.py:11-35's order — construct, .to(device), THEN load the checkpoint — with a
+    stats.json in <preprocessed_path>, as every real deployment has (model/modules.py:41-46)."""
+    import types
+
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd.checkpoint import get_model
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    cfg = wl.model_config("tiny")
+    pc = wl.preprocess_config()
+    os.makedirs(tmp_path / "pre")
+    with open(tmp_path / "pre" / "stats.json", "w") as f:
+        json.dump(wl.SYNTH_STATS, f)
+    pc["path"]["preprocessed_path"] = str(tmp_path / "pre")
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in wl.synth_state_dict(cfg, frames_per_phoneme=4.0).items()}
+    os.makedirs(tmp_path / "ckpt")
+    torch.save({"model": sd, "optimizer": {}}, tmp_path / "ckpt" / "7.pth.tar")
+    model = get_model(types.SimpleNamespace(restore_step=7), (pc, cfg, {"path": {"ckpt_path": str(tmp_path / "ckpt")}}),
+                      torch.device("cuda"))
+    direct = FastSpeech2Align(wl.preprocess_config(), cfg).to("cuda").eval()
+    direct.load_state_dict(sd)
+    sp, tx, ln, L = wl.synth_inputs(2, 12, seed=3, src_lens=[12, 9])
+    a = [torch.from_numpy(x).cuda() for x in (sp, tx, ln)]
+    with torch.no_grad():
+        o1, o2 = model(*a, L), direct(*a, L)
+    assert torch.equal(o1[1], o2[1]) and torch.equal(o1[9], o2[9]) and o1[1].shape[1] > 0
+
+    # random-init construction (model/fastspeech2_align.py:16-28): with stats.json and NO checkpoint the module runs
+    torch.manual_seed(0)
+    rnd = FastSpeech2Align(pc, cfg).to("cuda").eval()
+    with torch.no_grad():
+        o3 = rnd(*a, L)
+    assert o3[9].shape == (2,) and torch.isfinite(o3[0]).all() and torch.isfinite(o3[4]).all()
+    # without stats.json (the reference constructor raises FileNotFoundError there) the forward refuses
+    with pytest.raises(RuntimeError, match="weights not loaded"):
+        FastSpeech2Align(wl.preprocess_config(), cfg).to("cuda")(*a, L)
+
+
+@pytest.mark.gpu
+def test_token_id_out_of_range_raises_like_embedding():
+    """nn.Embedding raises IndexError for an id outside [0, n_vocab) (transformer/Models.py:89); the
+    kernels must not read out of bounds and the wrapper raises after its one host read."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    cfg = wl.model_config("tiny")
+    m = FastSpeech2Align(wl.preprocess_config(), cfg).to("cuda").eval()
+    m.load_state_dict(wl.synth_state_dict(cfg, frames_per_phoneme=4.0))
+    sp, tx, ln, L = wl.synth_inputs(3, 10, seed=1)
+    for bad in (wl.N_SYMBOLS + 1, 10 ** 12, -1):
+        t2 = tx.copy()
+        t2[1, 4] = bad
+        with pytest.raises(IndexError, match=r"utterance\(s\) \[1\]"):
+            m(torch.from_numpy(sp).cuda(), torch.from_numpy(t2).cuda(), torch.from_numpy(ln).cuda(), L)
+    t2 = tx.copy()
+    t2[0, 0] = wl.N_SYMBOLS  # the largest valid id
+    out = m(torch.from_numpy(sp).cuda(), torch.from_numpy(t2).cuda(), torch.from_numpy(ln).cuda(), L)
+    assert int(out[9].min()) >= 0
+
+
+@pytest.mark.gpu
+def test_adopted_arena_survives_a_device_rebind():
+    """a model whose weights arrived as packed bytes (adopt_arena, no host copy) must not keep a
+    stale arena pointer when its device handle changes; re-binding moves the bytes and the results stay identical."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    cfg = wl.model_config("tiny")
+    src = FastSpeech2Align(wl.preprocess_config(), cfg).to("cuda").eval()
+    src.load_state_dict(wl.synth_state_dict(cfg, frames_per_phoneme=4.0))
+    dst = FastSpeech2Align(wl.preprocess_config(), cfg).to("cuda").eval()
+    dst.arena_tensor().copy_(src.arena_tensor())
+    dst.adopt_arena()
+    sp, tx, ln, L = wl.synth_inputs(2, 9, seed=5)
+    a = [torch.from_numpy(x).cuda() for x in (sp, tx, ln)]
+    ref = src(*a, L)
+    assert torch.equal(dst(*a, L)[1], ref[1])
+    old = dst._arena
+    dst._device = None  # what a move from another device looks like to to(): the handle's device differs
+    dst.to("cuda")
+    assert dst._arena is not old and dst._arena.data_ptr() != old.data_ptr()
+    del old
+    torch.cuda.empty_cache()
+    assert torch.equal(dst(*a, L)[1], ref[1])

@@ -132,3 +132,113 @@ def test_workload_definition():
     _, tx2, _, _ = wl.synth_inputs(8, 10, seed=1)
     _, tx1, _, _ = wl.synth_inputs(4, 10, seed=1)
     assert np.array_equal(tx2[:4], tx1)
+
+
+def _stats_dir(tmp_path):
+    import json
+
+    import smart_nar_fast_tts_amd.workload as wl
+
+    os.makedirs(tmp_path / "pre", exist_ok=True)
+    with open(tmp_path / "pre" / "stats.json", "w") as f:
+        json.dump(wl.SYNTH_STATS, f)
+    pc = wl.preprocess_config()
+    pc["path"]["preprocessed_path"] = str(tmp_path / "pre")
+    return pc
+
+
+def test_stats_json_does_not_make_a_partial_state_dict(tmp_path, monkeypatch):
+    """with <preprocessed_path>/stats.json present — every real deployment — the constructor must not
+    leave a 2-key state dict behind that `.to(device)` then tries to upload (`missing keys: ...`) before a checkpoint
+    can be loaded (checkpoint.get_model: construct -> .to(device) -> load).  Host-side: the upload calls are recorded."""
+    import torch
+
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    cfg = wl.model_config("tiny")
+    m = FastSpeech2Align(_stats_dir(tmp_path), cfg)
+    assert len(m._sd) == 0 and not m._loaded and m._stats is not None
+    calls = []
+    monkeypatch.setattr(FastSpeech2Align, "_bind_arena", lambda self: calls.append("bind"))
+    monkeypatch.setattr(FastSpeech2Align, "_upload", lambda self, staged=False: calls.append("upload"))
+    m.to(torch.device("cuda", 0))       # get_model's order: .to(device) BEFORE load_state_dict
+    assert calls == []                   # nothing to upload yet, and no arena to re-bind
+    # a checkpoint WITHOUT the bin buffers still loads: stats.json supplies them as defaults
+    sd = {k: v for k, v in wl.synth_state_dict(cfg).items() if not k.endswith("_bins")}
+    m.load_state_dict(sd)
+    assert calls == ["upload"] and m._loaded
+    pb, eb = wl.variance_bins(cfg, wl.SYNTH_STATS)
+    assert np.array_equal(m._sd["variance_adaptor.pitch_bins"], pb) and np.array_equal(m._sd["variance_adaptor.energy_bins"], eb)
+    # a checkpoint's own bins override the stats defaults
+    sd2 = dict(wl.synth_state_dict(cfg))
+    sd2["variance_adaptor.pitch_bins"] = (pb * 2).astype(np.float32)
+    m.load_state_dict(sd2)
+    assert np.array_equal(m._sd["variance_adaptor.pitch_bins"], pb * 2)
+
+
+def test_load_state_dict_rejects_bad_keys_without_poisoning(tmp_path, monkeypatch):
+    """a key is validated by the native side BEFORE it is kept, so one unexpected key cannot poison
+    later uploads; a device change re-binds the arena (ADVICE medium) and re-uploads a loaded state dict."""
+    import torch
+
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    cfg = wl.model_config("tiny")
+    m = FastSpeech2Align(wl.preprocess_config(), cfg)
+    calls = []
+    monkeypatch.setattr(FastSpeech2Align, "_bind_arena", lambda self: calls.append("bind") or setattr(self, "_arena", object()))
+    monkeypatch.setattr(FastSpeech2Align, "_upload", lambda self, staged=False: calls.append("upload"))
+    m._device = torch.device("cuda", 0)
+    good = wl.synth_state_dict(cfg)
+    with pytest.raises(RuntimeError, match="unexpected key"):
+        m.load_state_dict(dict(good, **{"not.a.key": np.zeros(3, np.float32)}))
+    assert len(m._sd) == 0 and not m._loaded and calls == []
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        m.load_state_dict(dict(good, **{"mel_linear.bias": np.zeros(81, np.float32)}))
+    assert len(m._sd) == 0
+    m.load_state_dict(good)
+    assert m._loaded and calls == ["upload"] and "not.a.key" not in m._sd
+    m._arena = object()
+    m.to(torch.device("cuda", 1))  # device change: never keep the old device's arena bound
+    assert calls == ["upload", "bind", "upload"] and m._device == torch.device("cuda", 1) and len(m._ws) == 0
+
+
+def test_workspace_cache_is_bounded():
+    """scratch sets are keyed by stream handle; the cache must not grow with every new stream."""
+    from collections import OrderedDict
+
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    cap = 2 * FastSpeech2Align.MAX_WORKSPACE_STREAMS
+    ws = OrderedDict()
+    for i in range(50):  # what _workspace does per call, without a device
+        ws[("enc", i)] = i
+        ws.move_to_end(("enc", i))
+        while len(ws) > cap:
+            ws.popitem(last=False)
+    assert len(ws) == cap and ("enc", 49) in ws and ("enc", 0) not in ws
+
+
+def test_default_init_state_dict_follows_torch_initialisers():
+    """Random-init construction (model/fastspeech2_align.py:16-28): same key set and shapes as a checkpoint, torch's
+    default initialiser bounds, controlled by torch.manual_seed."""
+    import torch
+
+    import smart_nar_fast_tts_amd.workload as wl
+
+    cfg = wl.model_config("tiny")
+    torch.manual_seed(3)
+    a = wl.default_init_state_dict(cfg, wl.SYNTH_STATS)
+    torch.manual_seed(3)
+    b = wl.default_init_state_dict(cfg, wl.SYNTH_STATS)
+    ref = wl.synth_state_dict(cfg)
+    assert list(a) == list(ref) and all(a[k].shape == ref[k].shape for k in a)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    w = a["mel_decoder.layer_stack.0.pos_ffn.w_1.weight"]  # Conv1d [1024, 256, 9]: U(+-1/sqrt(256*9))
+    assert w.shape == (1024, 256, 9) and 0.99 / 48 < np.abs(w).max() <= 1 / 48
+    assert np.abs(a["mel_decoder.layer_stack.0.pos_ffn.w_1.bias"]).max() <= 1 / 48
+    assert (a["txt_encoder.src_word_emb.weight"][0] == 0).all() and abs(a["txt_encoder.src_word_emb.weight"][1:].std() - 1) < 0.05
+    assert (a["postnet.convolutions.2.1.running_var"] == 1).all() and (a["postnet.convolutions.2.1.running_mean"] == 0).all()
+    assert (a["variance_adaptor.pitch_predictor.conv_layer.layer_norm_1.weight"] == 1).all()
