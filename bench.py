@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — whole-job valid mel-frames/sec of the FastSpeech2 inference forward on N MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps 20 --warmup 5          (N > 1: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -13,6 +13,8 @@ collective; weights replicated by ONE RCCL broadcast before the timed region).  
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,6 +35,21 @@ ALGORITHMIC_KB_PER_FRAME = {"cfg1_single": 190.0, "cfg2_b16": 77.0, "cfg3_b128_s
                             "cfg5_longform": 70.0, "cfg5_longform_gaussian": 70.0}
 
 
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run the same command line as N ranks under torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1) and hand its output and exit code through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL / cross-process device memory need it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -44,6 +61,8 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="issue consecutive steps round-robin on this many HIP streams")
     ap.add_argument("--global-pad", action="store_true", help="pad every shard to the global max mel length (all-reduce MAX)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     import smart_nar_fast_tts_amd.workload as wl
     from smart_nar_fast_tts_amd import sharding
@@ -54,20 +73,26 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    # NS_BENCH_ONE_GPU=1 (test rigs only): every rank on cuda:0 with gloo, to exercise the N > 1 flow on a one-GPU box
+    # NS_BENCH_ONE_GPU=1 (test rigs only): every rank on cuda:0 with gloo, to exercise the N > 1 flow on a one-GPU box.
+    # The JSON says so (one_gpu_rig / devices / backend): such a line is a plumbing check, never a scaling number.
     one_gpu = os.environ.get("NS_BENCH_ONE_GPU") == "1"
+    n_dev = torch.cuda.device_count()
+    if not one_gpu and local_rank >= n_dev:
+        raise SystemExit(f"--gpus {args.gpus} but this box shows {n_dev} GPU(s): rank {rank} has no device "
+                         "(NS_BENCH_ONE_GPU=1 runs every rank on cuda:0 as a plumbing check)")
     dev_index = 0 if one_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    dist = None
+    dist, backend = None, None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if one_gpu else "nccl"  # "nccl" is RCCL on ROCm
         if one_gpu:
             dist.init_process_group(backend="gloo")
         else:
-            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     cfg_name, B_shard, L, fpp = wl.WORKLOADS[args.workload]
     cfg = wl.model_config(cfg_name)
@@ -122,18 +147,25 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)) if marks else None
-        k_ms, k_flops, k_launches = model.read_profile()
+        k_ms, k_flops, k_launches = model.read_profile(0)
+        by_kernel = {name: model.read_profile(i) for i, name in enumerate(model.PROFILE_SLOTS) if i > 0}
         model.profile_dominant_kernel(False)
 
     frames = int(out[9].sum().item())  # valid frames of this rank's shard (sum of mel_lens, never B*T_pad)
     T_pad = int(out[0].shape[1])
     stats = torch.tensor([elapsed, float(frames), float(T_pad)], dtype=torch.float64, device=dev)
+    devices = [{"rank": rank, "device": f"cuda:{dev_index}", "name": torch.cuda.get_device_name(dev)}]
+    world_seen = 1
     if dist is not None:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = stats.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed_max, frames_total, T_pad_max = float(tmax[0]), float(tsum[1]), int(tmax[2])
+        world_seen = dist.get_world_size()  # what the process group (RCCL on the GPU box) itself reports
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
     else:
         elapsed_max, frames_total, T_pad_max = elapsed, float(frames), T_pad
 
@@ -146,17 +178,25 @@ def main():
     value = frames_total * args.steps / elapsed_max
     flops_frame = wl.algorithmic_flops_per_frame(cfg, T_pad, L, fpp)
     achieved_tflops = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
+    # roofline.traffic: HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_profiles.sh)
+    # — only when that record was measured on THIS launch geometry (rows = B*T_pad, widths, kernel size); otherwise null
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
+    t = cfg["transformer"]
+    geom = {"rows": int(out[0].shape[0]) * T_pad, "d_model": t["decoder_hidden"], "d_inner": t["conv_filter_size"],
+            "k": t["conv_kernel_size"][0]}
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            rec = json.load(open(tpath))
+            if all(rec.get(k) == v for k, v in geom.items()):
+                traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     res = {
         "metric": "mel_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "devices": devices, "backend": backend, "world_size_seen_by_rccl": world_seen, "one_gpu_rig": one_gpu,
         "config": {"workload": f"{args.workload}{' (ragged lengths)' if args.ragged else ''}: LJSpeech config, batch {B_shard}/GPU x {args.gpus} GPU, phoneme_len {L}, "
                                f"T_pad {T_pad_max}, d_model {cfg['transformer']['decoder_hidden']}, "
                                f"{cfg['transformer']['encoder_layer']}+{cfg['transformer']['decoder_layer']} FFT layers, "
@@ -170,8 +210,21 @@ def main():
                      "frac": round(achieved_tflops / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                      "frac_of_measured_peak": round(achieved_tflops / F32_MFMA_MEASURED_TFLOPS, 4),
                      "launches": int(k_launches), "avg_launch_ms": round(k_ms / max(k_launches, 1), 4),
-                     "share_of_step_time": round((k_ms * 1e-3) / elapsed if elapsed > 0 else 0.0, 3)},
+                     "share_of_step_time": round((k_ms * 1e-3) / elapsed if elapsed > 0 else 0.0, 3),
+                     "geometry": geom},
     }
+    # the next two heaviest kernels, timed by the same in-forward HIP events (rank 0's shard): fused attention of the
+    # decoder stack (4*rows*T_pad*d flop per launch) and the PostNet's 512->512 k=5 convolutions
+    kdesc = {"attention": "k_attention (decoder self-attention: QK^T, key-mask, online softmax, PV)",
+             "postnet_mid": "k_conv_gemm (PostNet Conv1d k=5 512->512 + folded BatchNorm + tanh)"}
+    res["roofline_by_kernel"] = {"ffn_w1": {k: res["roofline"][k] for k in ("achieved", "frac", "launches", "avg_launch_ms",
+                                                                           "share_of_step_time")}}
+    for name, (ms, fl, n) in by_kernel.items():
+        tf = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        res["roofline_by_kernel"][name] = {"kernel": kdesc.get(name, name), "bound": "mfma", "achieved": round(tf, 2),
+                                           "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+                                           "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
+                                           "share_of_step_time": round((ms * 1e-3) / elapsed if elapsed > 0 else 0.0, 3)}
 
     # whole forward against both ceilings (MFMA primary, HBM secondary; vendor and measured peaks), per GPU
     kb = ALGORITHMIC_KB_PER_FRAME.get(args.workload)
@@ -228,13 +281,38 @@ def main():
         # The checker beside the measurement: same inputs through the HIP path and the oracle.  Free-running, the two may
         # pick different pitch/energy buckets for values that sit on a bucket edge (fp32 summation order);
         # with the oracle's pitch/energy handed to the HIP path as p_targets/e_targets the discrete choices are pinned.
+        # What the figures mean: durations / frame counts must be identical.  Free-running, any fp32 evaluation other than
+        # torch-CPU's may legally pick the neighbouring embedding row for a value within EDGE_REL (1e-5 relative) of a bin
+        # edge (model/modules.py:86-88,97-99); one such flip changes every frame of its utterance through global attention,
+        # which is what postnet_max_abs_free_running shows.  bucket_flips counts them, bucket_flips_off_edge counts flips
+        # that are NOT at an edge (must be 0: that would be a real error), and the pinned run is the parity number.
+        from oracle import parity
+
         chk = {"postnet_max_abs_free_running": None, "postnet_max_abs_buckets_pinned": None, "durations_equal": None}
         chk["durations_equal"] = bool(torch.equal(out[5].cpu(), ref[5]))
+        chk["duration_flips"] = int((out[5].cpu() != ref[5]).sum())
+        chk["frame_counts_equal"] = bool(torch.equal(out[9].cpu(), ref[9]))
         if out[1].shape == ref[1].shape:
-            chk["postnet_max_abs_free_running"] = float((out[1].cpu() - ref[1]).abs().max())
+            valid = ~ref[7].numpy()
+            pbins, ebins = w["variance_adaptor.pitch_bins"].numpy(), w["variance_adaptor.energy_bins"].numpy()
+            diff = (out[1].cpu() - ref[1]).abs()
+            chk["postnet_max_abs_free_running"] = float(diff.max())
+            chk["frames_over_1e-3_free_running"] = int(((diff.amax(dim=2) > 1e-3).numpy() & valid).sum())
+            chk["valid_frames"] = int(valid.sum())
             with torch.no_grad():
+                # energy is predicted on x + pitch_embedding: classify its buckets with the pitch decisions pinned
+                pin_p = model(speakers, texts, src_lens, Lmax, p_targets=ref[2].to(dev))
                 pin = model(speakers, texts, src_lens, Lmax, p_targets=ref[2].to(dev), e_targets=ref[3].to(dev))
+            fp = parity.classify_bucket_flips(out[2].cpu().numpy(), ref[2].numpy(), pbins, valid)
+            fe = parity.classify_bucket_flips(pin_p[3].cpu().numpy(), ref[3].numpy(), ebins, valid)
+            chk["bucket_decisions"] = 2 * int(valid.sum())
+            chk["bucket_flips"] = fp[0] + fe[0]
+            chk["bucket_flips_off_edge"] = fp[1] + fe[1]
+            chk["bucket_flips_by_more_than_one"] = fp[2] + fe[2]
+            chk["edge_rel_bound"] = parity.EDGE_REL
+            chk["pitch_max_abs"] = float((out[2].cpu() - ref[2]).abs().max())
             chk["postnet_max_abs_buckets_pinned"] = float((pin[1].cpu() - ref[1]).abs().max())
+            chk["frames_over_1e-3_buckets_pinned"] = int((((pin[1].cpu() - ref[1]).abs().amax(dim=2) > 1e-3).numpy() & valid).sum())
         res["check_vs_oracle"] = chk
     print(json.dumps(res), flush=True)
     if dist is not None:

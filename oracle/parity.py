@@ -1,0 +1,48 @@
+"""TEST INFRASTRUCTURE (checker only — never imported by the product package).
+
+Classification of the two discontinuous stages of the path, shared by the parity tests and by the checker that sits
+beside bench.py's measurement:
+
+* ``round(exp(log_d) - 1)``                 model/modules.py:132-135   -> duration flips
+* ``torch.bucketize(pitch | energy, bins)``  model/modules.py:86-88,97-99 -> bucket flips
+
+Any fp32 evaluation whose summation order differs from torch's CPU kernels may take the other branch when the value
+sits within rounding noise of the boundary.  A flip is *legal* only there: the reference's own value must lie within
+``EDGE_REL`` (relative) of a bin edge.  A flip anywhere else is a real error.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+EDGE_REL = 1e-5  # same bound as tests/golden/make_golden.py PE_MARGIN; observed fp32 noise on pitch/energy is 2-4e-6 relative
+
+
+def edge_distance(values: np.ndarray, bins: np.ndarray) -> np.ndarray:
+    """Absolute distance of every value to its nearest bin edge."""
+    v = np.asarray(values, dtype=np.float64)
+    b = np.asarray(bins, dtype=np.float64)
+    i = np.clip(np.searchsorted(b, v, side="left"), 1, len(b) - 1)
+    return np.minimum(np.abs(v - b[i - 1]), np.abs(v - b[i]))
+
+
+def edge_rel(values: np.ndarray, bins: np.ndarray) -> np.ndarray:
+    """Distance to the nearest bin edge relative to max(|value|, 1) (what the fixtures store as p_edge_rel / e_edge_rel)."""
+    return edge_distance(values, bins) / np.maximum(np.abs(np.asarray(values, dtype=np.float64)), 1.0)
+
+
+def bucketize(values: np.ndarray, bins: np.ndarray) -> np.ndarray:
+    """torch.bucketize(values, bins, right=False) for finite values."""
+    return np.searchsorted(np.asarray(bins), np.asarray(values), side="left")
+
+
+def classify_bucket_flips(got: np.ndarray, ref: np.ndarray, bins: np.ndarray, valid: np.ndarray, edge_rel_ref=None):
+    """Compare the bucket decisions of ``got`` with those of the reference values ``ref`` on the ``valid`` frames.
+
+    Returns ``(flips, off_edge, by_more_than_one)``: how many decisions differ, how many of those differ although the
+    reference value is NOT within EDGE_REL of an edge (must be 0), and how many moved by more than one bucket (must be 0)."""
+    gi, ri = bucketize(got, bins), bucketize(ref, bins)
+    flip = (gi != ri) & valid
+    rel = edge_rel(ref, bins) if edge_rel_ref is None else edge_rel_ref
+    off = flip & ~(rel < EDGE_REL)
+    far = flip & (np.abs(gi - ri) > 1)
+    return int(flip.sum()), int(off.sum()), int(far.sum())

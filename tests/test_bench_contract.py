@@ -1,5 +1,6 @@
 """bench.py's output contract (the driver parses the LAST stdout line as JSON): every required key with the right
-type, one short run on the GPU box, CPU-baseline leg included."""
+type, one short run on the GPU box, CPU-baseline leg included; the plain `python bench.py --gpus N` form launches
+its own ranks."""
 import json
 import os
 import subprocess
@@ -10,12 +11,20 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _run(args, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                       cwd=ROOT, env=e)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly ONE JSON line (rank 0 only)"
+    return json.loads(lines[-1])
+
+
 @pytest.mark.gpu
 def test_bench_json_contract():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"],
-                       capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads(r.stdout.strip().splitlines()[-1])
+    d = _run(["--gpus", "1", "--steps", "3", "--warmup", "1"])
     assert d["metric"] == "mel_frames_per_sec" and d["unit"] == "frames/s"
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -24,12 +33,83 @@ def test_bench_json_contract():
     assert d["config"]["workload"].startswith("cfg2_b16") and "model" not in d["config"]
     # value is whole-job valid frames / wall
     assert abs(d["value"] - d["config"]["valid_frames_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert d["one_gpu_rig"] is False and d["backend"] is None and d["world_size_seen_by_rccl"] == 1
+    assert len(d["devices"]) == 1 and d["devices"][0]["device"] == "cuda:0"
     ro = d["roofline"]
     assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s")
     assert ro["peak"] > 0 and ro["achieved"] > 0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
-    assert ro["traffic"] is None or ro["traffic"] > 0
     assert ro["launches"] == 3 * 4  # the dominant kernel runs once per decoder layer per timed step
+    # traffic is the committed PMC figure ONLY when it was measured on this launch geometry
+    rec = json.load(open(os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")))
+    same = all(rec.get(k) == v for k, v in ro["geometry"].items())
+    assert (ro["traffic"] == rec["hbm_bytes_per_launch"]) if same else (ro["traffic"] is None)
+    rb = d["roofline_by_kernel"]
+    assert set(rb) == {"ffn_w1", "attention", "postnet_mid"}
+    assert rb["attention"]["launches"] == 3 * 4 and rb["postnet_mid"]["launches"] == 3 * 3
+    for k in ("attention", "postnet_mid"):
+        assert 0 < rb[k]["frac"] <= 1.0 and rb[k]["bound"] == "mfma" and abs(rb[k]["frac"] - rb[k]["achieved"] / rb[k]["peak"]) < 1e-3
+    # the three timed kernels cannot add up to more than the step
+    assert sum(rb[k]["share_of_step_time"] for k in rb) <= 1.0
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "frames/s" and cb["sample"]
     chk = d["check_vs_oracle"]
-    assert chk["durations_equal"] is True and chk["postnet_max_abs_buckets_pinned"] < 1e-3
+    assert chk["durations_equal"] is True and chk["duration_flips"] == 0 and chk["frame_counts_equal"] is True
+    assert chk["postnet_max_abs_buckets_pinned"] < 1e-3 and chk["frames_over_1e-3_buckets_pinned"] == 0
+    # the free-running figure is explained by legal bucket flips: none of them away from a bin edge, none by more than one
+    assert chk["bucket_flips_off_edge"] == 0 and chk["bucket_flips_by_more_than_one"] == 0
+    assert 0 <= chk["bucket_flips"] <= chk["bucket_decisions"] // 100
+    if chk["bucket_flips"] == 0:
+        assert chk["postnet_max_abs_free_running"] < 1e-3 and chk["frames_over_1e-3_free_running"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_other_workload_has_no_stale_traffic():
+    """roofline.traffic is a measurement of ONE launch geometry; a different workload must report null, not config 2's number."""
+    d = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "cfg1_single", "--no-cpu-baseline"])
+    assert d["roofline"]["traffic"] is None and d["roofline"]["geometry"]["rows"] != 16160
+
+
+@pytest.mark.gpu
+def test_bench_plain_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (the driver's N > 1 form may be either): bench.py re-executes
+    itself under torch.distributed.run.  On the one-GPU test box both ranks share cuda:0 over gloo, and the line says so."""
+    env = {"NS_BENCH_ONE_GPU": "1"}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env)
+    assert d["n_gpus"] == 2 and d["world_size_seen_by_rccl"] == 2 and d["one_gpu_rig"] is True and d["backend"] == "gloo"
+    assert [x["rank"] for x in d["devices"]] == [0, 1] and all(x["device"] == "cuda:0" for x in d["devices"])
+    assert d["config"]["global_batch"] == 32 and d["scaling"] == "weak"
+    # without the rig switch a 2-rank run on a 1-GPU box must refuse instead of silently sharing a device
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                            "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode != 0 and "no device" in (r.stdout + r.stderr)
+
+
+def test_self_launch_command_line(monkeypatch):
+    """CPU: the re-exec command is the driver's own torchrun form (one node, N ranks, 127.0.0.1 rendezvous)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    assert bench.self_launch(4) == 7
+    c = seen["cmd"]
+    assert c[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in c
+    assert c[c.index("--master-addr") + 1] == "127.0.0.1" and int(c[c.index("--master-port") + 1]) > 0
+    assert c[-4:] == ["--gpus", "4", "--steps", "3"] and c[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

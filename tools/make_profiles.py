@@ -77,6 +77,8 @@ gui = m[(kname, wgs, "GRBM_GUI_ACTIVE")][0]
 dur = m[(kname, wgs, "GRBM_GUI_ACTIVE")][1]
 d = {
     "kernel": f"{kname} (decoder FFN w_1: Conv1d k=9 256->1024, bias+ReLU), {wgs} workgroups, rows B*T_pad = {rows}",
+    # geometry of the measured launch: bench.py reports roofline.traffic only for a run whose dominant kernel matches it
+    "rows": rows, "d_model": 256, "d_inner": 1024, "k": 9, "workgroups": int(wgs),
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / MFMA counters, one pass each, `python bench.py --steps 5 --warmup 2`; per-launch averages",
     "fetch_size_kb_raw": f[(kname, wgs, "FETCH_SIZE")][0], "write_size_kb_raw": w[(kname, wgs, "WRITE_SIZE")][0],
     "fetch_bytes_corrected_x2": fetch_b, "write_bytes": write_b, "hbm_bytes_per_launch": fetch_b + write_b,
