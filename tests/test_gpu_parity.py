@@ -129,6 +129,13 @@ def test_per_op_vs_reference_golden(name):
     e["dec_ffn"] = close(ops.positionwise_ffn(m, "mel_decoder.layer_stack.0.pos_ffn", dev(cap["dec0_ffn.in0"])),
                          cap["dec0_ffn.out0"], OP_TOL, "a6 dec ffn")
     e["txt_encoder"] = close(ops.txt_encoder(m, dev(z["texts"]), src_lens), cap["enc.out0"], OP_TOL, "a3 txt_encoder")
+    # a7 FFTBlock.forward (transformer/Layers.py:39-48) called directly: these fixtures are 1+1-layer models, so layer 0's
+    # input is the attention hook's input and its output (both masked_fill's applied) is the stack's output
+    assert cfg["transformer"]["encoder_layer"] == 1 and cfg["transformer"]["decoder_layer"] == 1
+    e["enc_fft_block"] = close(ops.fft_block(m, "txt_encoder.layer_stack.0", dev(cap["enc0_attn.in0"]), src_lens),
+                               cap["enc.out0"], OP_TOL, "a7 enc FFTBlock")
+    e["dec_fft_block"] = close(ops.fft_block(m, "mel_decoder.layer_stack.0", dev(cap["dec0_attn.in0"]), mel_lens),
+                               cap["dec.out0"], OP_TOL, "a7 dec FFTBlock")
     e["dur_pred"] = close(ops.variance_predictor(m, "variance_adaptor.duration_predictor", dev(cap["dur_pred.in0"]), src_lens),
                           cap["dur_pred.out0"], OP_TOL, "a8 duration predictor")
     e["pitch_pred"] = close(ops.variance_predictor(m, "variance_adaptor.pitch_predictor", dev(cap["pitch_pred.in0"]), mel_lens),
@@ -227,7 +234,11 @@ def test_kat_gaussian_upsampling():
 @pytest.mark.parametrize("name", ["pin_cfg1_single", "pin_cfg2_b16", "pin_cfg3_b128_sharded", "pin_cfg4_d512",
                                   "pin_cfg5_longform"])
 def test_baseline_configs_vs_reference_pins(name):
-    """BASELINE.json's configs at FULL size against numbers produced by the reference itself.
+    """BASELINE.json's configs against numbers produced by the reference itself, at the sizes the committed fixtures
+    cover: configs 1 and 2 at FULL size (B=1 L=100; B=16 L=128), config 3 as ONE of its eight 16-utterance shards,
+    config 4 (d=512, 6+6 layers, 8 heads) at B=8 of its 64, config 5 (T~3900) at B=2 of its 8 — the reference needs
+    minutes and tens of GB for the full B=64 / B=8 shapes; those run against the oracle in
+    test_full_size_cfg4_cfg5_vs_oracle below.  The batch size in use is printed.
     Free run: every duration and frame count exactly; pitch/energy within tolerance; bucket choices identical
     except where the reference value sits on a bin edge to within fp32 noise (counted and printed).
     Then, with the reference's own pitch/energy values handed in as p_targets/e_targets (so both sides take the
@@ -251,38 +262,99 @@ def test_baseline_configs_vs_reference_pins(name):
         close(out[0][:, ::st], z["output_sub"], MEL_TOL, "mel (free run)")
     e1 = close(tf[0][:, ::st], z["output_sub"], MEL_TOL, "mel")
     e2 = close(tf[1][:, ::st], z["postnet_output_sub"], MEL_TOL, "postnet mel")
-    print(name, "T", out[0].shape[1], "frames", int(z["mel_lens"].sum()), "edge bucket flips in free run", n_flip,
+    print(name, "B", int(meta["B"]), "L", int(meta["L"]), "T", out[0].shape[1], "frames", int(z["mel_lens"].sum()),
+          "edge bucket flips in free run", n_flip,
           "mel err", e1, "postnet err", e2)
+
+
+def _half_dist(log_d):
+    """distance of exp(log_d) - 1 to the nearest .5 (the rounding boundary of model/modules.py:132-135)"""
+    return np.abs((np.exp(np.asarray(log_d, dtype=np.float64)) - 1.0) % 1.0 - 0.5)
+
+
+def _oracle_case_with_margin(w, cfg, B, L, seed, lens=None, margin=2e-4, tries=40, **kw):
+    """First input seed >= `seed` whose ORACLE durations all sit >= margin away from a rounding boundary, so that an
+    fp32 summation-order difference cannot flip one: the comparison below then always runs (no silent skip)."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from oracle import fs2_oracle as orc
+
+    for s in range(seed, seed + tries):
+        inp = wl.synth_inputs(B, L, seed=s, src_lens=lens)
+        with torch.no_grad():
+            ref = orc.forward(w, cfg, torch.from_numpy(inp[0]), torch.from_numpy(inp[1]), torch.from_numpy(inp[2]), inp[3], **kw)
+        valid = ~ref[6].numpy()
+        if not valid.any() or _half_dist(ref[4].numpy())[valid].min() >= margin:
+            return s, inp, ref
+    raise AssertionError(f"no input seed in [{seed}, {seed + tries}) keeps every duration {margin} away from a rounding boundary")
+
+
+def _screened_full_batch(w, cfg, B, L, seed, margin=2e-4):
+    """Full-size configs: the oracle forward takes 2-20 s there, so instead of re-drawing whole batches, screen 2*B candidate
+    utterances with the oracle's encoder + duration predictor only (7 % of the flops; an unpadded utterance's durations
+    depend on its own tokens alone) and keep the first B whose durations all sit >= margin away from a
+    rounding boundary.  Returns the batch and the oracle's full forward on it."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from oracle import fs2_oracle as orc
+
+    sp, tx, ln, Lmax = wl.synth_inputs(2 * B, L, seed=seed)
+    t = cfg["transformer"]
+    keep = []
+    with torch.no_grad():
+        for lo in range(0, 2 * B, 16):
+            txc, lnc = torch.from_numpy(tx[lo:lo + 16]), torch.from_numpy(ln[lo:lo + 16])
+            mask = orc.get_mask_from_lengths(lnc, Lmax)
+            x = orc.txt_encoder(w, txc, mask, t["encoder_head"], cfg["max_seq_len"])
+            hd = _half_dist(orc.variance_predictor(w, "variance_adaptor.duration_predictor", x, mask).numpy())
+            keep += [lo + i for i in range(hd.shape[0]) if hd[i].min() >= margin]
+    assert len(keep) >= B, f"only {len(keep)} of {2 * B} candidate utterances keep {margin} from the rounding boundaries"
+    keep = keep[:B]
+    inp = (sp[keep], np.ascontiguousarray(tx[keep]), ln[keep], Lmax)
+    with torch.no_grad():
+        ref = orc.forward(w, cfg, torch.from_numpy(inp[0]), torch.from_numpy(inp[1]), torch.from_numpy(inp[2]), Lmax)
+    assert _half_dist(ref[4].numpy()).min() >= margin / 2
+    return inp, ref
+
+
+def _pinned_vs_oracle(m, w, cfg, inp, ref, what, **kw):
+    """Durations / frame counts / masks identical; pitch within 2e-3 with only at-edge bucket flips; then energy, mel and
+    PostNet mel on EVERY frame with both sides taking the same bucket decisions (the oracle's values as targets)."""
+    from oracle import fs2_oracle as orc
+    from oracle import parity
+
+    with torch.no_grad():
+        out = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3], **kw)
+    assert np.array_equal(out[5].cpu().numpy(), ref[5].numpy()), (what, "durations differ")
+    assert np.array_equal(out[9].cpu().numpy(), ref[9].numpy()), (what, "frame counts differ")
+    assert np.array_equal(out[7].cpu().numpy(), ref[7].numpy()), (what, "mel masks differ")
+    close(out[4], ref[4].numpy(), 1e-4, what + " log durations")
+    close(out[2], ref[2].numpy(), 2e-3, what + " pitch")
+    valid = ~ref[7].numpy()
+    fp = parity.classify_bucket_flips(out[2].cpu().numpy(), ref[2].numpy(), w["variance_adaptor.pitch_bins"].numpy(), valid)
+    assert fp[1] == 0 and fp[2] == 0, (what, "pitch bucket flips away from a bin edge / by more than one", fp)
+    pc, ec = kw.get("p_control", 1.0), kw.get("e_control", 1.0)
+    with torch.no_grad():
+        # the oracle's free-run predictions are already scaled by p/e_control; as targets they are bucketized as is
+        tf = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3], p_targets=ref[2].cuda(), e_targets=ref[3].cuda())
+        pp = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3], p_targets=ref[2].cuda(), e_control=ec)
+    fe = parity.classify_bucket_flips(pp[3].cpu().numpy(), ref[3].numpy(), w["variance_adaptor.energy_bins"].numpy(), valid)
+    assert fe[1] == 0 and fe[2] == 0, (what, "energy bucket flips away from a bin edge / by more than one", fe)
+    return {"edge_flips": fp[0] + fe[0], "energy": close(tf[3] * ec, ref[3].numpy(), MEL_TOL, what + " energy"),
+            "mel": close(tf[0], ref[0].numpy(), MEL_TOL, what + " mel"),
+            "postnet": close(tf[1], ref[1].numpy(), MEL_TOL, what + " postnet mel"), "out": out}
 
 
 def test_full_size_vs_oracle_and_properties():
     """Config 2 at full size, every frame: HIP path vs the oracle run on this box's host cores, plus
     size-independent properties (mask/length consistency, zeroed pad frames of the mel projection input)."""
-    import smart_nar_fast_tts_amd.workload as wl
     from oracle import fs2_oracle as orc
 
     meta = dict(config="ljspeech", weight_seed=0, frames_per_phoneme=8.0, dur_weight_scale=0.25)
     cfg, sd, m = gpu_model(meta)
-    inp = wl.synth_inputs(16, 128, seed=3)
-    with torch.no_grad():
-        ref = orc.forward(orc.to_torch_weights(sd), cfg, *[torch.from_numpy(a) if isinstance(a, np.ndarray) else a for a in inp])
-        out = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3])
-    torch.cuda.synchronize()
-    half = np.abs((np.exp(ref[4].numpy().astype(np.float64)) - 1.0) % 1.0 - 0.5)
-    flips = np.flatnonzero(out[5].cpu().numpy().ravel() != ref[5].numpy().ravel())
-    # a flip is only legitimate where the oracle itself sits on a rounding boundary to within fp32 summation noise
-    assert np.all(half.ravel()[flips] < 5e-5), ("duration flips away from rounding boundaries", flips[:8])
-    if flips.size == 0:
-        assert np.array_equal(out[9].cpu().numpy(), ref[9].numpy())
-        close(out[2], ref[2].numpy(), 2e-3, "pitch")
-        # same discrete bucket decisions on both sides (see bucket_flips): hand the oracle's values in as targets
-        with torch.no_grad():
-            tf = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3], p_targets=ref[2].cuda(), e_targets=ref[3].cuda())
-            rf = orc.forward(orc.to_torch_weights(sd), cfg, torch.from_numpy(inp[0]), torch.from_numpy(inp[1]),
-                             torch.from_numpy(inp[2]), inp[3], p_targets=ref[2], e_targets=ref[3])
-        close(tf[3], rf[3].numpy(), MEL_TOL, "energy")
-        print("config 2 full size, every frame: mel", close(tf[0], rf[0].numpy(), MEL_TOL, "mel"),
-              "postnet", close(tf[1], rf[1].numpy(), MEL_TOL, "postnet mel"))
+    w = orc.to_torch_weights(sd)
+    inp, ref = _screened_full_batch(w, cfg, 16, 128, seed=3)
+    r = _pinned_vs_oracle(m, w, cfg, inp, ref, "config 2 full size")
+    out = r.pop("out")
+    print("config 2 full size (B=16, L=128), every frame:", r)
     mel_lens = out[9].cpu().numpy()
     T = out[0].shape[1]
     assert T == mel_lens.max()
@@ -293,35 +365,44 @@ def test_full_size_vs_oracle_and_properties():
     assert np.all(out[3].cpu().numpy()[out[7].cpu().numpy()] == 0.0)
 
 
-def test_edge_cases():
-    """Ragged / minimal inputs the reference handles: B=1,L=1; heavy phoneme-side padding; p/e control."""
+@pytest.mark.parametrize("workload", ["cfg4_d512", "cfg5_longform"])
+def test_full_size_cfg4_cfg5_vs_oracle(workload):
+    """BASELINE configs 4 (d=512, 6+6 layers, 8 heads, B=64: 64 x ~1010 rows through the 512-wide tiles) and 5 (B=8,
+    T~3900: 31 query tiles x 122 key tiles per head) at their FULL batch sizes, every frame, against the oracle with
+    the bucket decisions pinned (the reference-generated pins cover B=8 / B=2 of these shapes)."""
     import smart_nar_fast_tts_amd.workload as wl
+    from oracle import fs2_oracle as orc
+
+    cfg_name, B, L, fpp = wl.WORKLOADS[workload]
+    meta = dict(config=cfg_name, weight_seed=0, frames_per_phoneme=fpp, dur_weight_scale=0.25)
+    cfg, sd, m = gpu_model(meta)
+    w = orc.to_torch_weights(sd)
+    inp, ref = _screened_full_batch(w, cfg, B, L, seed=0)
+    r = _pinned_vs_oracle(m, w, cfg, inp, ref, workload)
+    out = r.pop("out")
+    print(workload, "B", B, "L", L, "T_pad", out[0].shape[1], "rows", B * out[0].shape[1], "valid frames", int(ref[9].sum()), r)
+    assert out[0].shape[0] == B and (out[0].shape[1] > 3000 if workload == "cfg5_longform" else B * out[0].shape[1] > 60000)
+    _MODEL.clear()  # 329 MB of d=512 weights + ~1 GB of scratch: give it back before the next test
+
+
+def test_edge_cases():
+    """Ragged / minimal inputs the reference handles: B=1,L=1; heavy phoneme-side padding; p/e control.  Every case is
+    compared (inputs are re-drawn until no oracle duration sits on a rounding boundary) and the count is asserted."""
     from oracle import fs2_oracle as orc
 
     meta = dict(config="tiny", weight_seed=0, frames_per_phoneme=4.0, dur_weight_scale=0.25)
     cfg, sd, m = gpu_model(meta)
     w = orc.to_torch_weights(sd)
     cases = [(1, 1, None), (2, 5, [5, 1]), (4, 33, [33, 2, 17, 32]), (3, 130, [130, 64, 129])]
+    ran = 0
     for B, L, lens in cases:
-        inp = wl.synth_inputs(B, L, seed=21, src_lens=lens)
         for pc, ec in ((1.0, 1.0), (1.3, 0.7)):
-            with torch.no_grad():
-                ref = orc.forward(w, cfg, torch.from_numpy(inp[0]), torch.from_numpy(inp[1]), torch.from_numpy(inp[2]), inp[3],
-                                  p_control=pc, e_control=ec)
-                out = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3], p_control=pc, e_control=ec)
-            half = np.abs((np.exp(ref[4].numpy().astype(np.float64)) - 1.0) % 1.0 - 0.5)
-            valid = ~ref[6].numpy()
-            if half[valid].min() < 1e-4:
-                continue  # boundary case, covered by the flip classification test
-            assert np.array_equal(out[5].cpu().numpy(), ref[5].numpy()), (B, L)
-            assert np.array_equal(out[9].cpu().numpy(), ref[9].numpy()), (B, L)
-            close(out[2], ref[2].numpy(), 2e-3, "pitch")
-            # the oracle's free-run predictions are already scaled by p/e_control; handed in as targets they are
-            # bucketized as is, which pins both sides to the same embedding rows
-            with torch.no_grad():
-                tf = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3], p_targets=ref[2].cuda(), e_targets=ref[3].cuda())
-            close(tf[3] * ec, ref[3].numpy(), MEL_TOL, "energy")
-            close(tf[1], ref[1].numpy(), MEL_TOL, f"postnet mel B={B} L={L}")
+            seed, inp, ref = _oracle_case_with_margin(w, cfg, B, L, seed=21, lens=lens, p_control=pc, e_control=ec)
+            r = _pinned_vs_oracle(m, w, cfg, inp, ref, f"B={B} L={L} p_control={pc} e_control={ec}", p_control=pc, e_control=ec)
+            r.pop("out")
+            ran += 1
+            print(f"edge case B={B} L={L} lens={lens} controls=({pc},{ec}) seed={seed}:", r)
+    assert ran == 2 * len(cases), ran
 
 
 def test_all_zero_durations_give_empty_output():
@@ -443,7 +524,7 @@ def test_random_shapes_vs_oracle():
 
     rs = np.random.RandomState(2024)
     cfg = wl.model_config("tiny")
-    checked = 0
+    checked, worst = 0, 0.0
     for fpp in (1.0, 3.0):
         sd = wl.synth_state_dict(cfg, seed=1, frames_per_phoneme=fpp)
         w = orc.to_torch_weights(sd)
@@ -454,24 +535,18 @@ def test_random_shapes_vs_oracle():
             L = int(rs.choice([1, 2, 5, 31, 32, 33, 63, 64, 65, 100, 129, 200]))
             lens = np.maximum(1, rs.randint(1, L + 1, size=B))
             lens[rs.randint(B)] = L
-            inp = wl.synth_inputs(B, L, seed=int(rs.randint(1 << 20)), src_lens=lens)
-            with torch.no_grad():
-                ref = orc.forward(w, cfg, torch.from_numpy(inp[0]), torch.from_numpy(inp[1]), torch.from_numpy(inp[2]), inp[3])
-                out = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3])
-            close(out[4], ref[4].numpy(), 1e-4, f"log durations B={B} L={L}")
-            half = np.abs((np.exp(ref[4].numpy().astype(np.float64)) - 1.0) % 1.0 - 0.5)
-            flips = out[5].cpu().numpy() != ref[5].numpy()
-            assert np.all(half[flips] < 5e-5), (B, L, lens.tolist())
-            if flips.any() or int(ref[9].max()) == 0:
-                continue
-            assert np.array_equal(out[9].cpu().numpy(), ref[9].numpy())
-            with torch.no_grad():
-                tf = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3], p_targets=ref[2].cuda(), e_targets=ref[3].cuda())
-            close(tf[3], ref[3].numpy(), MEL_TOL, f"energy B={B} L={L}")
-            close(tf[0], ref[0].numpy(), MEL_TOL, f"mel B={B} L={L} lens={lens.tolist()}")
-            close(tf[1], ref[1].numpy(), MEL_TOL, f"postnet mel B={B} L={L}")
+            # re-draw the token ids (not the shape) until no oracle duration sits on a rounding boundary: every shape is compared
+            seed, inp, ref = _oracle_case_with_margin(w, cfg, B, L, seed=int(rs.randint(1 << 20)), lens=lens)
+            if int(ref[9].max()) == 0:  # all durations zero: T = 0, nothing to compare beyond the shapes
+                with torch.no_grad():
+                    out = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3])
+                assert out[0].shape[1] == 0 and np.array_equal(out[5].cpu().numpy(), ref[5].numpy())
+            else:
+                r = _pinned_vs_oracle(m, w, cfg, inp, ref, f"fpp={fpp} B={B} L={L} lens={lens.tolist()}")
+                worst = max(worst, r["mel"], r["postnet"])
             checked += 1
-    assert checked >= 8
+    print("random shapes compared:", checked, "worst mel/postnet max-abs", worst)
+    assert checked == 12, checked
 
 
 def test_large_batch_replicas_are_identical():
