@@ -1,0 +1,50 @@
+// Kernel lab: determinism + fp64 reference check of k_attention (same input twice must give the same bits; sampled rows vs a
+// double-precision softmax(QK^T/sqrt(dk))V).   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -I../../smart-nar_fast_tts_amd/csrc attn_det.hip -o attn_det
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "attention.hip"
+using namespace ns;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+int main() {
+  struct Shape { const char* name; int B, S, H, dk; } shapes[] = {
+    {"cfg2 dec  B16 S1010 H2 dk128", 16, 1010, 2, 128}, {"cfg5 dec  B8 S3880 H2 dk128", 8, 3880, 2, 128},
+    {"cfg4 dec  B8 S1045 H8 dk64  ", 8, 1045, 8, 64},  {"cfg1 dec  B1 S788 H2 dk128 ", 1, 788, 2, 128},
+    {"cfg2 enc  B16 S128 H2 dk128 ", 16, 128, 2, 128}, {"odd      B3 S333 H2 dk128  ", 3, 333, 2, 128}};
+  srand(1);
+  for (auto& s : shapes) {
+    const int d = s.H * s.dk; size_t n = (size_t)s.B * s.S * 3 * d, no = n / 3;
+    std::vector<float> h(n); for (auto& v : h) v = ((float)rand() / RAND_MAX * 2 - 1);
+    std::vector<long long> hl(s.B); for (int b = 0; b < s.B; ++b) hl[b] = s.S - (b * 97) % (s.S / 2);
+    float *q, *o1, *o2, *scr; long long* dl;
+    CK(hipMalloc(&q, n * 4)); CK(hipMalloc(&o1, no * 4)); CK(hipMalloc(&o2, no * 4)); CK(hipMalloc(&dl, s.B * 8));
+    CK(hipMemcpy(q, h.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dl, hl.data(), s.B * 8, hipMemcpyHostToDevice));
+    const size_t scr_floats = (size_t)ATT_SPLIT_MAX * ((size_t)s.B * s.S * d + 2 * (size_t)s.B * s.S * s.H);
+    CK(hipMalloc(&scr, scr_floats * 4));
+    CK(hipMemset(o1, 0xff, no * 4)); CK(hipMemset(o2, 0x7f, no * 4));
+    CK(launch_attention(q, dl, s.B, s.S, s.H, s.dk, o1, scr, scr_floats, 0));
+    CK(launch_attention(q, dl, s.B, s.S, s.H, s.dk, o2, scr, scr_floats, 0));
+    CK(hipDeviceSynchronize());
+    std::vector<float> a(no), b(no);
+    CK(hipMemcpy(a.data(), o1, no * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), o2, no * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0; for (size_t i = 0; i < no; ++i) bad += memcmp(&a[i], &b[i], 4) != 0;
+    // fp64 reference on a few rows
+    double maxerr = 0;
+    for (int t = 0; t < 24; ++t) {
+      const int bb = rand() % s.B, hh = rand() % s.H, qq = rand() % s.S;
+      const int len = (int)hl[bb];
+      std::vector<double> sc(len); double mx = -1e300;
+      const float* base = h.data() + (size_t)bb * s.S * 3 * d;
+      for (int k = 0; k < len; ++k) { double acc = 0; for (int c = 0; c < s.dk; ++c) acc += (double)base[(size_t)qq * 3 * d + hh * s.dk + c] * base[(size_t)k * 3 * d + d + hh * s.dk + c]; sc[k] = acc / sqrt((double)s.dk); mx = fmax(mx, sc[k]); }
+      double den = 0; for (int k = 0; k < len; ++k) { sc[k] = exp(sc[k] - mx); den += sc[k]; }
+      for (int c = 0; c < s.dk; ++c) { double acc = 0; for (int k = 0; k < len; ++k) acc += sc[k] * base[(size_t)k * 3 * d + 2 * d + hh * s.dk + c];
+        maxerr = fmax(maxerr, fabs(acc / den - a[((size_t)bb * s.S + qq) * d + hh * s.dk + c])); }
+    }
+    printf("%s  run-to-run bit mismatches %zu of %zu   max err vs fp64 on 24 rows %.2e\n", s.name, bad, no, maxerr);
+    CK(hipFree(q)); CK(hipFree(o1)); CK(hipFree(o2)); CK(hipFree(scr)); CK(hipFree(dl));
+  }
+  return 0;
+}
