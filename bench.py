@@ -151,6 +151,23 @@ def main():
         by_kernel = {name: model.read_profile(i) for i, name in enumerate(model.PROFILE_SLOTS) if i > 0}
         model.profile_dominant_kernel(False)
 
+        # Secondary, outside the timed region above: the same K steps issued round-robin on two HIP streams (what
+        # batching.synthesize(streams=2) does for consecutive batches), so the small-grid phase 1 and the host read of
+        # step i+1 overlap the chip-filling phase 2 of step i.  Reported beside the headline value, never as it.
+        pipelined = None
+        if streams is None and args.gpus == 1:
+            ps = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            for i in range(2):
+                with torch.cuda.stream(ps[i]):
+                    model(speakers, texts, src_lens, Lmax, max_mel_len=pad_fn)
+            torch.cuda.synchronize()
+            t0p = time.perf_counter()
+            for i in range(args.steps):
+                with torch.cuda.stream(ps[i % 2]):
+                    model(speakers, texts, src_lens, Lmax, max_mel_len=pad_fn)
+            torch.cuda.synchronize()
+            pipelined = time.perf_counter() - t0p
+
     frames = int(out[9].sum().item())  # valid frames of this rank's shard (sum of mel_lens, never B*T_pad)
     T_pad = int(out[0].shape[1])
     stats = torch.tensor([elapsed, float(frames), float(T_pad)], dtype=torch.float64, device=dev)
@@ -236,6 +253,10 @@ def main():
                          "frac_hbm_peak": None if kb is None else round(kb * 1e3 * value / args.gpus / 1e9 / HBM_PEAK_GBS, 4),
                          "frac_hbm_measured": None if kb is None else round(kb * 1e3 * value / args.gpus / 1e9 / HBM_MEASURED_GBS, 4)}
 
+    if pipelined:
+        res["pipelined"] = {"streams": 2, "steps": args.steps, "ms_per_step": round(pipelined / args.steps * 1e3, 4),
+                            "value": round(frames_total * args.steps / pipelined, 1), "unit": "frames/s",
+                            "note": "consecutive steps round-robin on 2 HIP streams, measured after the timed region; not the headline value"}
     if step_ms:
         res["step_ms_spread"] = {"p50": round(step_ms[len(step_ms) // 2], 3), "min": round(step_ms[0], 3),
                                  "max": round(step_ms[-1], 3), "n": len(step_ms)}

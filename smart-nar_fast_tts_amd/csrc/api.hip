@@ -791,7 +791,6 @@ extern "C" int ns_op_bucketize(const float* values, int n, const float* bins, in
 extern "C" int ns_op_gaussian_upsampling(const float* x, const float* durations, int B, int L, int D, int T, int T_out, float* out,
                                          float* s, float* w, void* stream) {
   if (T_out < T) return fail("ns_op_gaussian_upsampling: T_out < T");
-  if ((size_t)L * sizeof(float) > 60000) return fail("ns_op_gaussian_upsampling: L too large");
   NS_HIP(launch_gaussian_upsampling(x, durations, B, L, D, T, T_out, out, s, w, nullptr, (hipStream_t)stream));
   return 0;
 }

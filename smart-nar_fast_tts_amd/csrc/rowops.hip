@@ -306,7 +306,7 @@ hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int
 // GaussianUpsampling.forward (model/modules.py:166-192; defined but never called by the reference forward,
 // SURVEY.md F1).  c = cumsum(d) - d/2 ; w[b,l,t] = exp(-0.01 (t-c)^2) / (sum_l exp(..) + 1e-20) ; out = w^T x.
 // t spans [0, T) with T = max_b sum(d): rows past an utterance's own length are NOT zeroed; rows in
-// [T, T_out) are the zero padding of pad(output, max_len).  One workgroup per output frame.
+// [T, T_out) are the zero padding of pad(output, max_len).
 __global__ __launch_bounds__(256) void k_gauss_centers(const float* __restrict__ dur, int L, float* __restrict__ centers,
                                                         float* __restrict__ s) {
   // sequential fp32 cumsum per utterance, as torch.cumsum on CPU accumulates
@@ -320,41 +320,90 @@ __global__ __launch_bounds__(256) void k_gauss_centers(const float* __restrict__
   }
   s[b] = e;
 }
+// One workgroup = 32 consecutive output frames of one utterance x all D channels: out[32, D] = w^T[32, L] x[L, D] on the
+// fp32 matrix cores.  The normalised weights of the 32 frames are staged in LDS one chunk of GU_LC phonemes at a time
+// (row stride GU_LC + 1: the A-fragment reads — 32 frames at one phoneme — hit 32 different banks); the B operand
+// x[l, n0 + lane] is read straight from L2 (x[b] is re-read by every tile of its utterance and stays resident).
+// v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain, so walking l upwards reproduces the serial
+// `acc = fmaf(w[l], x[l], acc)` of a scalar loop bit for bit.  Cost O(T L D / 32) matrix instructions instead of O(T L D)
+// scalar FMAs with one L2 sweep of x per FRAME (the round-1 kernel).
+typedef float f32x16r __attribute__((ext_vector_type(16)));
+constexpr int GU_LC = 256;
 __global__ __launch_bounds__(256) void k_gauss_upsample(const float* __restrict__ x, const float* __restrict__ centers, int L,
                                                          int D, int T, int T_out, float* __restrict__ out,
                                                          float* __restrict__ w, const long long* __restrict__ own_len) {
-  extern __shared__ float wl[];  // [L]
-  __shared__ float red[4];
-  const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  float* orow = out + ((size_t)b * T_out + t) * D;
-  // own_len == nullptr: the reference module's behaviour (frames past an utterance's own length are NOT zeroed);
-  // own_len given: the wired-in length regulator zero-pads them like LengthRegulator + pad() does
-  if (t >= T || (own_len && (long long)t >= own_len[b])) {
-    for (int c = tid; c < D; c += 256) orow[c] = 0.f;
-    return;
-  }
+#if defined(__HIP_DEVICE_COMPILE__)  // the MFMA builtin does not exist in the host pass; it only needs the stub
+  __shared__ float wt[32 * (GU_LC + 1)];
+  __shared__ float w2s[32];
+  const int b = blockIdx.y, t0 = blockIdx.x * 32, tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tt = tid & 31, sub = tid >> 5;  // frame of this thread inside the tile, and which eighth of the phonemes it walks
+  const float* cb = centers + (size_t)b * L;
+  const float tf = (float)(t0 + tt);
+  // pass 1: w2[t] = sum_l exp(-0.01 (t - c_l)^2) + 1e-20 (model/modules.py:184-186)
   float part = 0.f;
-  for (int l = tid; l < L; l += 256) {
-    const float df = (float)t - centers[(size_t)b * L + l];
-    const float e = expf(-0.01f * (df * df));
-    wl[l] = e;
-    part += e;
+  for (int l = sub; l < L; l += 8) {
+    const float df = tf - cb[l];
+    part += expf(-0.01f * (df * df));
   }
-  part = wave_sum(part);
-  if (lane == 0) red[wid] = part;
+  wt[tt * 9 + sub] = part;
   __syncthreads();
-  const float w2 = ((red[0] + red[1]) + (red[2] + red[3])) + 1e-20f;
-  for (int l = tid; l < L; l += 256) {
-    const float wv = wl[l] / w2;
-    wl[l] = wv;
-    if (w) w[((size_t)b * L + l) * T + t] = wv;
+  if (tid < 32) {
+    const float* p8 = wt + tid * 9;
+    w2s[tid] = (((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]))) + 1e-20f;
   }
   __syncthreads();
-  for (int c = tid; c < D; c += 256) {
-    float acc = 0.f;
-    for (int l = 0; l < L; ++l) acc = fmaf(wl[l], x[((size_t)b * L + l) * D + c], acc);
-    orow[c] = acc;
+  const float w2 = w2s[tt];
+  // frames this tile must leave as zeros: t >= T is pad(output, max_len); with own_len (the wired-in length regulator)
+  // also t >= the utterance's own length.  own_len == nullptr keeps the reference module's behaviour (NOT zeroed).
+  const int t_lim = own_len ? (int)(own_len[b] < (long long)T ? own_len[b] : (long long)T) : T;
+  const int nt = (D + 31) / 32;  // 32-channel tiles (the last may be partial); wave wv owns tiles wv, wv+4, ... (up to 4 per pass)
+  for (int nbase = 0; nbase < nt; nbase += 16) {
+    f32x16r acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int lc = 0; lc < L; lc += GU_LC) {
+      const int ln = min(GU_LC, L - lc), lpad = (ln + 1) & ~1;
+      for (int j = sub; j < lpad; j += 8) {
+        float wvv = 0.f;
+        if (j < ln) {
+          const float df = tf - cb[lc + j];
+          wvv = expf(-0.01f * (df * df)) / w2;
+          if (w && nbase == 0 && t0 + tt < T) w[((size_t)b * L + lc + j) * T + t0 + tt] = wvv;
+        }
+        wt[tt * (GU_LC + 1) + j] = wvv;
+      }
+      __syncthreads();
+      const float* arow = wt + (lane & 31) * (GU_LC + 1) + (lane >> 5);
+      const float* xrow = x + ((size_t)b * L + lc + (lane >> 5)) * D + (lane & 31);
+      for (int l2 = 0; l2 < lpad; l2 += 2) {
+        const float av = arow[l2];
+        const bool in = lc + l2 + (lane >> 5) < L;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int tile = nbase + wv + 4 * j;
+          if (tile < nt) {
+            const float bv = (in && tile * 32 + (lane & 31) < D) ? xrow[(size_t)l2 * D + tile * 32] : 0.f;
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int tile = nbase + wv + 4 * j;
+      if (tile >= nt) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (t < T_out && tile * 32 + (lane & 31) < D) out[((size_t)b * T_out + t) * D + tile * 32 + (lane & 31)] = t < t_lim ? acc[j][r] : 0.f;
+      }
+    }
   }
+#endif
 }
 hipError_t launch_gaussian_upsampling(const float* x, const float* dur, int B, int L, int D, int T, int T_out, float* out,
                                       float* s, float* w, const long long* own_len, hipStream_t st) {
@@ -362,8 +411,7 @@ hipError_t launch_gaussian_upsampling(const float* x, const float* dur, int B, i
   // s holds B sums followed by B*L Gaussian centres (scratch)
   float* centers = s + B;
   hipLaunchKernelGGL(k_gauss_centers, dim3(B), dim3(64), 0, st, dur, L, centers, s);
-  hipLaunchKernelGGL(k_gauss_upsample, dim3(T_out, B), dim3(256), L * sizeof(float), st, x, centers, L, D, T, T_out, out, w,
-                     own_len);
+  hipLaunchKernelGGL(k_gauss_upsample, dim3((T_out + 31) / 32, B), dim3(256), 0, st, x, centers, L, D, T, T_out, out, w, own_len);
   return hipGetLastError();
 }
 

@@ -9,6 +9,8 @@ weights; ``prefix`` is the reference's module path (e.g. ``"mel_decoder.layer_st
 """
 from __future__ import annotations
 
+import math
+
 import torch
 
 from . import _lib
@@ -146,7 +148,8 @@ def gaussian_upsampling(x, durations, max_len=None):
     lib = _lib.load()
     B, L, D = x.shape
     x, durations = x.contiguous(), durations.contiguous().float()
-    T = int(durations.sum(dim=-1).max().item())  # torch.max(s) in the reference, also a host sync there (arange)
+    # torch.arange(0, torch.max(s)) in the reference (also a host sync there): ceil(max s) frames for a fractional sum
+    T = int(math.ceil(durations.sum(dim=-1).max().item()))
     T_out = int(max_len) if max_len else T
     out = torch.empty(B, T_out, D, dtype=torch.float32, device=x.device)
     s = torch.empty(B * (L + 1), dtype=torch.float32, device=x.device)

@@ -231,6 +231,28 @@ def test_kat_gaussian_upsampling():
     close(out40, z["out_maxlen40"], 5e-6, "gaussian out (max_len=40)")
 
 
+@pytest.mark.parametrize("B,L,D", [(2, 300, 256), (1, 513, 512), (3, 7, 256), (2, 257, 64), (2, 40, 24), (1, 9, 600)])
+def test_gaussian_upsampling_scales_with_L(B, L, D):
+    """a12 beyond the reference KAT's sizes: phoneme axes longer than one LDS chunk of weights (256), odd lengths (the
+    MFMA walks phonemes two at a time), 64..512 channels, zero and fractional durations — against the oracle's
+    GaussianUpsampling (model/modules.py:166-192) on the same inputs."""
+    from oracle import fs2_oracle as orc
+    from smart_nar_fast_tts_amd import ops
+
+    rs = np.random.RandomState(L)
+    x = rs.standard_normal((B, L, D)).astype(np.float32)
+    d = np.maximum(rs.randint(-1, 6, size=(B, L)).astype(np.float32) + rs.choice([0.0, 0.5], size=(B, L)).astype(np.float32), 0.0)
+    ref_out, ref_s, ref_w = orc.gaussian_upsampling(torch.from_numpy(x), torch.from_numpy(d), None)
+    out, s_, w = ops.gaussian_upsampling(dev(x), dev(d))
+    assert np.array_equal(s_.cpu().numpy().reshape(-1), ref_s.numpy().reshape(-1))
+    e_w = close(w, ref_w.numpy(), 1e-6, "gaussian w")
+    e_o = close(out, ref_out.numpy(), 2e-5, "gaussian out")
+    T = ref_out.shape[1]
+    padded, _, _ = ops.gaussian_upsampling(dev(x), dev(d), T + 37)
+    assert padded.shape[1] == T + 37 and torch.equal(padded[:, :T], out) and float(padded[:, T:].abs().max()) == 0.0
+    print(f"gaussian B={B} L={L} D={D} T={T}: w err {e_w:.1e} out err {e_o:.1e}")
+
+
 @pytest.mark.parametrize("name", ["pin_cfg1_single", "pin_cfg2_b16", "pin_cfg3_b128_sharded", "pin_cfg4_d512",
                                   "pin_cfg5_longform"])
 def test_baseline_configs_vs_reference_pins(name):
