@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libnarfs2.so")
-SOURCES = ["gemm_conv.hip", "attention.hip", "rowops.hip", "api.hip"]
+SOURCES = ["gemm_conv.hip", "gemm_bf16x3.hip", "attention.hip", "rowops.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 # attention keeps its O^T / S^T accumulators in architectural VGPRs (gfx950 has one unified 512-entry file): the
 # online softmax touches them with VALU ops, and in AGPR form hipcc shuttles all 64+16 registers through

@@ -28,9 +28,10 @@ static int fail(const std::string& s) { g_err = s; return 1; }
 
 namespace {
 
-struct LayerW { size_t qkv_w, qkv_b, fc_w, fc_b, ln1_g, ln1_b, w1, w1_b, w2, w2_b, ln2_g, ln2_b; };
+struct LayerW { size_t qkv_w, qkv_b, fc_w, fc_b, ln1_g, ln1_b, w1, w1_b, w2, w2_b, ln2_g, ln2_b, w1_b3; };  // w1_b3: bf16x3 planes or NO_B3
 struct PredW { size_t c1, c1_b, ln1_g, ln1_b, c2, c2_b, ln2_g, ln2_b, lin_w, lin_b; int cin; };
-struct PostW { size_t w, b; int cin, cout; };
+struct PostW { size_t w, b, w_b3; int cin, cout; };
+constexpr size_t NO_B3 = (size_t)-1;
 
 struct Arena {
   size_t n = 0;  // floats
@@ -66,7 +67,7 @@ static void expect(ns_model* m, const std::string& name, std::vector<int64_t> sh
   Staged s; s.shape = std::move(shape); s.optional = optional; m->staged[name] = std::move(s);
 }
 
-static void plan_stack(ns_model* m, const char* prefix, int n_layer, int d, std::vector<LayerW>& out) {
+static void plan_stack(ns_model* m, const char* prefix, int n_layer, int d, std::vector<LayerW>& out, bool decoder) {
   const ns_config& c = m->cfg;
   for (int i = 0; i < n_layer; ++i) {
     std::string p = std::string(prefix) + ".layer_stack." + std::to_string(i);
@@ -89,6 +90,8 @@ static void plan_stack(ns_model* m, const char* prefix, int n_layer, int d, std:
     L.w1 = m->ar.take((size_t)c.d_inner * c.ffn_k1 * d); L.w1_b = m->ar.take(c.d_inner);
     L.w2 = m->ar.take((size_t)d * c.ffn_k2 * c.d_inner); L.w2_b = m->ar.take(d);
     L.ln2_g = m->ar.take(d); L.ln2_b = m->ar.take(d);
+    // opt-in bf16x3 mode: three bf16 planes of the (packed) k=9 weights of the DECODER stack — 1.5x their fp32 size
+    L.w1_b3 = (c.matmul_bf16x3 && decoder) ? m->ar.take(((size_t)3 * c.d_inner * c.ffn_k1 * d + 1) / 2) : NO_B3;
     out.push_back(L);
   }
 }
@@ -110,6 +113,7 @@ extern "C" int ns_create(const ns_config* cfg, ns_model** out) {
   if (!(c.ffn_k1 & 1) || !(c.ffn_k2 & 1) || !(c.vp_kernel & 1) || !(c.postnet_k & 1))
     return fail("ns_create: kernel sizes must be odd");
   if (c.length_regulator != 0 && c.length_regulator != 1) return fail("ns_create: length_regulator must be 0 (hard) or 1 (gaussian)");
+  if (c.matmul_bf16x3 != 0 && c.matmul_bf16x3 != 1) return fail("ns_create: matmul_bf16x3 must be 0 (fp32) or 1 (bf16x3)");
   if (c.vp_kernel != 3) return fail("ns_create: variance predictor conv1d_2 hard-codes padding=1 (model/modules.py:267); kernel_size must be 3");
   ns_model* m = new ns_model();
   m->cfg = c;
@@ -120,8 +124,8 @@ extern "C" int ns_create(const ns_config* cfg, ns_model** out) {
   m->emb = m->ar.take((size_t)c.n_vocab * d);
   m->enc_pos = m->ar.take((size_t)npos * d);
   m->dec_pos = m->ar.take((size_t)npos * c.d_dec);
-  plan_stack(m, "txt_encoder", c.n_enc_layer, d, m->enc);
-  plan_stack(m, "mel_decoder", c.n_dec_layer, c.d_dec, m->dec);
+  plan_stack(m, "txt_encoder", c.n_enc_layer, d, m->enc, false);
+  plan_stack(m, "mel_decoder", c.n_dec_layer, c.d_dec, m->dec, true);
   const int F = c.vp_filter, K = c.vp_kernel;
   for (int i = 0; i < 3; ++i) {
     std::string p = std::string("variance_adaptor.") + kPredNames[i] + "_predictor";
@@ -160,6 +164,7 @@ extern "C" int ns_create(const ns_config* cfg, ns_model** out) {
     for (const char* s : {"weight", "bias", "running_mean", "running_var"}) expect(m, p + ".1." + s, {cout});
     PostW w; w.cin = cin; w.cout = cout;
     w.w = m->ar.take((size_t)cout * c.postnet_k * cin); w.b = m->ar.take(cout);
+    w.w_b3 = (c.matmul_bf16x3 && cin == c.postnet_dim && cout == c.postnet_dim) ? m->ar.take(((size_t)3 * cout * c.postnet_k * cin + 1) / 2) : NO_B3;
     m->post.push_back(w);
   }
   *out = m;
@@ -269,6 +274,11 @@ extern "C" int ns_finalize_weights(ns_model* m, void* stream) {
       cp(L.fc_w, p + ".slf_attn.fc.weight"); cp(L.fc_b, p + ".slf_attn.fc.bias");
       cp(L.ln1_g, p + ".slf_attn.layer_norm.weight"); cp(L.ln1_b, p + ".slf_attn.layer_norm.bias");
       pack_conv(S(p + ".pos_ffn.w_1.weight"), c.d_inner, d, c.ffn_k1, &img[L.w1]); cp(L.w1_b, p + ".pos_ffn.w_1.bias");
+      if (L.w1_b3 != NO_B3) {  // the SAME packed fp32 values, split exactly into three bf16 planes
+        const size_t n = (size_t)c.d_inner * c.ffn_k1 * d;
+        unsigned short* pl = reinterpret_cast<unsigned short*>(&img[L.w1_b3]);
+        split_weights_b3(&img[L.w1], n, pl, pl + n, pl + 2 * n);
+      }
       pack_conv(S(p + ".pos_ffn.w_2.weight"), d, c.d_inner, c.ffn_k2, &img[L.w2]); cp(L.w2_b, p + ".pos_ffn.w_2.bias");
       cp(L.ln2_g, p + ".pos_ffn.layer_norm.weight"); cp(L.ln2_b, p + ".pos_ffn.layer_norm.bias");
     }
@@ -303,6 +313,11 @@ extern "C" int ns_finalize_weights(ns_model* m, void* stream) {
       img[w.b + o] = (float)(((double)cb[o] - (double)mu[o]) * sc[o] + (double)b[o]);
     }
     pack_conv(S(p + ".0.conv.weight"), w.cout, w.cin, c.postnet_k, &img[w.w], sc.data());
+    if (w.w_b3 != NO_B3) {
+      const size_t n = (size_t)w.cout * c.postnet_k * w.cin;
+      unsigned short* pl = reinterpret_cast<unsigned short*>(&img[w.w_b3]);
+      split_weights_b3(&img[w.w], n, pl, pl + n, pl + 2 * n);
+    }
   }
   hipStream_t st = (hipStream_t)stream;
   NS_HIP(hipMemcpyAsync(m->arena, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, st));
@@ -377,13 +392,20 @@ static int check_ready(const ns_model* m) {
 }
 
 static int gemm(const float* X, int ldx, const float* W, const float* bias, const float* resid, int ldr, float* Y, int ldy,
-                int M, int N, int Cin, int KW, int S, int act, hipStream_t st, const RowEpilogue* epi = nullptr, int epi_mode = EPI_NONE) {
+                int M, int N, int Cin, int KW, int S, int act, hipStream_t st, const RowEpilogue* epi = nullptr, int epi_mode = EPI_NONE,
+                const unsigned short* Wb3 = nullptr) {
   ConvGemm p;
   memset(&p, 0, sizeof(p));
   p.X = X; p.ldx = ldx; p.W = W; p.bias = bias; p.resid = resid; p.ldr = ldr; p.Y = Y; p.ldy = ldy;
   p.M = M; p.N = N; p.Cin = Cin; p.KW = KW; p.pad = (KW - 1) / 2; p.S = S; p.act = act;
   p.epi = epi ? epi_mode : EPI_NONE;
   if (epi) p.e = *epi;
+  // opt-in bf16x3 planes exist for this weight AND the launch is large enough for the 128-row tiles: split-bf16 matrix cores
+  if (Wb3 && !epi && conv_gemm_b3_ok(M, N, Cin, KW)) {
+    p.Wb3 = Wb3;
+    NS_HIP(launch_conv_gemm_b3(p, st));
+    return 0;
+  }
   NS_HIP(launch_conv_gemm(p, st));
   return 0;
 }
@@ -462,7 +484,8 @@ static int ffn(const ns_model* m, const LayerW& L, int d, const float* x, const 
   {
     ProfScope ps(m, 0, st, 2.0 * (double)M * (double)c.ffn_k1 * (double)d * (double)c.d_inner);
     NS_TRY(ps.begin());
-    NS_TRY(gemm(x, d, m->P(L.w1), m->P(L.w1_b), nullptr, 0, sc.hid, c.d_inner, M, c.d_inner, d, c.ffn_k1, S, ACT_RELU, st));
+    NS_TRY(gemm(x, d, m->P(L.w1), m->P(L.w1_b), nullptr, 0, sc.hid, c.d_inner, M, c.d_inner, d, c.ffn_k1, S, ACT_RELU, st, nullptr, EPI_NONE,
+                L.w1_b3 != NO_B3 ? reinterpret_cast<const unsigned short*>(m->P(L.w1_b3)) : nullptr));
     NS_TRY(ps.end());
   }
   return gemm_ln(sc.hid, c.d_inner, m->P(L.w2), m->P(L.w2_b), x, sc.t1, out, M, d, c.d_inner, c.ffn_k2, S, ACT_NONE, m->P(L.ln2_g),
@@ -530,7 +553,8 @@ static int postnet(const ns_model* m, const float* mel, int B, int T, const floa
     ProfScope ps(m, 2, st, 2.0 * (double)M * (double)c.postnet_k * (double)w.cin * (double)w.cout);
     if (mid) NS_TRY(ps.begin());
     NS_TRY(gemm(cur, ld, m->P(w.w), m->P(w.b), last ? resid : nullptr, c.n_mel, dst, w.cout, M, w.cout, w.cin, c.postnet_k, T,
-                last ? ACT_NONE : ACT_TANH, st));
+                last ? ACT_NONE : ACT_TANH, st, nullptr, EPI_NONE,
+                w.w_b3 != NO_B3 ? reinterpret_cast<const unsigned short*>(m->P(w.w_b3)) : nullptr));
     if (mid) NS_TRY(ps.end());
     cur = dst;
     ld = w.cout;

@@ -29,6 +29,7 @@ struct RowEpilogue {
 struct ConvGemm {
   const float* X; int ldx;
   const float* W;               // packed [N][KW*Cin]
+  const unsigned short* Wb3;    // optional: the same weights as three bf16 planes [3][N][KW*Cin] (gemm_bf16x3.hip), else nullptr
   const float* bias;            // [N] or nullptr
   const float* resid; int ldr;  // [M, N] or nullptr
   float* Y; int ldy;
@@ -38,6 +39,10 @@ struct ConvGemm {
   RowEpilogue e;
 };
 hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st);
+// opt-in "bf16x3" precision mode (gemm_bf16x3.hip): same contraction from an exact 3-way bf16 split of both operands
+bool conv_gemm_b3_ok(int M, int N, int Cin, int KW);
+hipError_t launch_conv_gemm_b3(const ConvGemm& p, hipStream_t st);
+void split_weights_b3(const float* w, size_t n, unsigned short* hi, unsigned short* mid, unsigned short* lo);
 // true when launch_conv_gemm has a full-row tile for this shape (so p.epi may be set); otherwise the caller runs the
 // plain GEMM followed by the row kernel
 bool conv_gemm_row_epilogue_ok(int M, int N, int Cin);

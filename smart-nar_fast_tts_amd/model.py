@@ -42,6 +42,9 @@ def config_struct(preprocess_config: dict, model_config: dict) -> _lib.NsConfig:
         # EXTENSION key (absent from the reference's model.yaml): "gaussian" wires the reference's unused
         # GaussianUpsampling module in place of the hard LengthRegulator
         length_regulator={"hard": 0, "gaussian": 1}[model_config.get("length_regulator", "hard")],
+        # EXTENSION key: "bf16x3" opts the large decoder-FFN / PostNet contractions into the split-bf16 matrix-core path
+        # (include/nar_fs2.h ns_config.matmul_bf16x3); "fp32" (default) is the reference's arithmetic everywhere
+        matmul_bf16x3={"fp32": 0, "bf16x3": 1}[model_config.get("matmul", "fp32")],
     )
 
 

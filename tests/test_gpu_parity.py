@@ -627,3 +627,36 @@ def test_ragged_batch_vs_oracle():
     close(tf[3], ref[3].numpy(), MEL_TOL, "energy")
     print("ragged: mel", close(tf[0], ref[0].numpy(), MEL_TOL, "mel (all rows, padded included)"),
           "postnet", close(tf[1], ref[1].numpy(), MEL_TOL, "postnet mel (all rows, padded included)"))
+
+
+def test_bf16x3_mode_vs_oracle_and_fp32_path():
+    """OPT-IN precision mode (ns_config.matmul_bf16x3, csrc/gemm_bf16x3.hip): the decoder FFN k=9 convolutions and the
+    PostNet 512->512 convolutions computed from an exact 3-way bf16 split on the bf16 matrix cores.  Config 2 at full size:
+    every discrete output identical to the oracle's (they are all upstream of those layers), mel / PostNet mel within the
+    same 1e-3 bar with the buckets pinned, and within fp32 noise of the exact-fp32 HIP path — but NOT bit-identical to it
+    (if it were, the mode would not have run)."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from oracle import fs2_oracle as orc
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    meta = dict(config="ljspeech", weight_seed=0, frames_per_phoneme=8.0, dur_weight_scale=0.25)
+    cfg, sd, m32 = gpu_model(meta)
+    w = orc.to_torch_weights(sd)
+    inp, ref = _screened_full_batch(w, cfg, 16, 128, seed=3)
+    mb3 = FastSpeech2Align(wl.preprocess_config(), dict(cfg, matmul="bf16x3")).to("cuda").eval()
+    mb3.load_state_dict(sd)
+    assert mb3._lib.ns_arena_bytes(mb3._h) > m32._lib.ns_arena_bytes(m32._h)  # the weight planes are there
+    r = _pinned_vs_oracle(mb3, w, cfg, inp, ref, "bf16x3 mode, config 2 full size")
+    r.pop("out")
+    with torch.no_grad():
+        a = m32(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3], p_targets=ref[2].cuda(), e_targets=ref[3].cuda())
+        b = mb3(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3], p_targets=ref[2].cuda(), e_targets=ref[3].cuda())
+    for i in (2, 3, 4, 5, 9):  # pitch, energy, log durations, durations, frame counts: untouched by the mode
+        assert torch.equal(a[i], b[i]), NAMES[i]
+    d = float((a[1] - b[1]).abs().max())
+    assert 0.0 < d < 5e-5, d
+    print("bf16x3 mode vs oracle:", r, " vs the exact-fp32 HIP path, PostNet mel max-abs:", d)
+    # small launches fall back to the fp32 kernels: a tiny batch through the bf16x3 model is bit-identical to the fp32 model
+    sp, tx, ln, L = wl.synth_inputs(2, 20, seed=1)
+    with torch.no_grad():
+        assert torch.equal(m32(dev(sp), dev(tx), dev(ln), L)[1], mb3(dev(sp), dev(tx), dev(ln), L)[1])
