@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2_b16", help="cfg2_b16 | cfg4_d512 | cfg5_longform | cfg5_longform_gaussian | cfg1_single")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="profiling runs: only warm-up + timed steps (no latency leg, no pipelined leg, no CPU baseline), so that a "
+                         "kernel trace holds exactly (warmup + steps) forwards of the workload")
     ap.add_argument("--ragged", action="store_true", help="ragged utterance lengths instead of the uniform BASELINE batch")
     ap.add_argument("--streams", type=int, default=1, help="issue consecutive steps round-robin on this many HIP streams")
     ap.add_argument("--global-pad", action="store_true", help="pad every shard to the global max mel length (all-reduce MAX)")
@@ -161,7 +164,7 @@ def main():
         # batching.synthesize(streams=2) does for consecutive batches), so the small-grid phase 1 and the host read of
         # step i+1 overlap the chip-filling phase 2 of step i.  Reported beside the headline value, never as it.
         pipelined = None
-        if streams is None and args.gpus == 1:
+        if streams is None and args.gpus == 1 and not args.no_extras:
             ps = [torch.cuda.Stream(device=dev) for _ in range(2)]
             for i in range(2):
                 with torch.cuda.stream(ps[i]):
@@ -278,7 +281,7 @@ def main():
     if step_ms:
         res["step_ms_spread"] = {"p50": round(step_ms[len(step_ms) // 2], 3), "min": round(step_ms[0], 3),
                                  "max": round(step_ms[-1], 3), "n": len(step_ms)}
-    if args.gpus == 1:
+    if args.gpus == 1 and not args.no_extras:
         # p50 per-utterance latency (the second half of BASELINE.json's metric), config 1: B=1, L=100
         c1, B1, L1, f1 = wl.WORKLOADS["cfg1_single"]
         if c1 == cfg_name and f1 == fpp:  # same architecture AND same synthetic duration bias (mel_len 788)
@@ -296,7 +299,7 @@ def main():
             res["latency"] = {"workload": "cfg1_single: B=1, phoneme_len 100", "p50_ms": round(float(np.median(lat)), 3),
                               "min_ms": round(min(lat), 3), "max_ms": round(max(lat), 3), "mel_len": int(o1[9][0]), "n": len(lat)}
 
-    if args.gpus == 1 and not args.no_cpu_baseline:
+    if args.gpus == 1 and not args.no_cpu_baseline and not args.no_extras:
         # CPU baseline beside it: the oracle (a torch-CPU restatement of the reference forward, "port") on this box's
         # host cores, same workload, bounded to ~10-30 s.
         from oracle import fs2_oracle as orc

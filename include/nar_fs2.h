@@ -44,8 +44,9 @@ typedef struct ns_config {
   int32_t length_regulator; /* 0 = LengthRegulator (what the reference wires, model/modules.py:22); 1 = EXTENSION: the
                                reference's unused GaussianUpsampling (model/modules.py:162-192) in its place */
   int32_t matmul_bf16x3;    /* 0 = every contraction on the fp32 matrix cores (the default, the reference's arithmetic);
-                               1 = OPT-IN: the decoder FFN k=9 convolutions and the PostNet 512->512 convolutions (everything
-                               downstream of the discrete duration / bucket decisions that is large enough) run from an exact
+                               1 = OPT-IN: the decoder stack's projections / FFN convolutions and the PostNet 512->512
+                               convolutions (downstream of every discrete duration / bucket decision; only launches large
+                               enough to fill the chip with 64..256-row tiles, smaller ones stay fp32) run from an exact
                                3-way bf16 split of both operands on the bf16 matrix cores, 6 products, fp32 accumulation:
                                fp32-sized error, different bits, ~1.8x faster on those layers (csrc/gemm_bf16x3.hip) */
 } ns_config;

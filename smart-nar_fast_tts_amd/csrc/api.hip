@@ -28,7 +28,7 @@ static int fail(const std::string& s) { g_err = s; return 1; }
 
 namespace {
 
-struct LayerW { size_t qkv_w, qkv_b, fc_w, fc_b, ln1_g, ln1_b, w1, w1_b, w2, w2_b, ln2_g, ln2_b, w1_b3; };  // w1_b3: bf16x3 planes or NO_B3
+struct LayerW { size_t qkv_w, qkv_b, fc_w, fc_b, ln1_g, ln1_b, w1, w1_b, w2, w2_b, ln2_g, ln2_b, qkv_b3, fc_b3, w1_b3, w2_b3; };  // *_b3: bf16x3 planes or NO_B3
 struct PredW { size_t c1, c1_b, ln1_g, ln1_b, c2, c2_b, ln2_g, ln2_b, lin_w, lin_b; int cin; };
 struct PostW { size_t w, b, w_b3; int cin, cout; };
 constexpr size_t NO_B3 = (size_t)-1;
@@ -91,7 +91,13 @@ static void plan_stack(ns_model* m, const char* prefix, int n_layer, int d, std:
     L.w2 = m->ar.take((size_t)d * c.ffn_k2 * c.d_inner); L.w2_b = m->ar.take(d);
     L.ln2_g = m->ar.take(d); L.ln2_b = m->ar.take(d);
     // opt-in bf16x3 mode: three bf16 planes of the (packed) k=9 weights of the DECODER stack — 1.5x their fp32 size
-    L.w1_b3 = (c.matmul_bf16x3 && decoder) ? m->ar.take(((size_t)3 * c.d_inner * c.ffn_k1 * d + 1) / 2) : NO_B3;
+    // (decoder stack only: everything upstream of the duration / pitch / energy decisions stays exact fp32)
+    const bool b3 = c.matmul_bf16x3 && decoder;
+    auto planes = [&](size_t n) { return b3 ? m->ar.take((3 * n + 1) / 2) : NO_B3; };
+    L.qkv_b3 = planes((size_t)3 * d * d);
+    L.fc_b3 = planes((size_t)d * d);
+    L.w1_b3 = planes((size_t)c.d_inner * c.ffn_k1 * d);
+    L.w2_b3 = planes((size_t)d * c.ffn_k2 * c.d_inner);
     out.push_back(L);
   }
 }
@@ -274,13 +280,18 @@ extern "C" int ns_finalize_weights(ns_model* m, void* stream) {
       cp(L.fc_w, p + ".slf_attn.fc.weight"); cp(L.fc_b, p + ".slf_attn.fc.bias");
       cp(L.ln1_g, p + ".slf_attn.layer_norm.weight"); cp(L.ln1_b, p + ".slf_attn.layer_norm.bias");
       pack_conv(S(p + ".pos_ffn.w_1.weight"), c.d_inner, d, c.ffn_k1, &img[L.w1]); cp(L.w1_b, p + ".pos_ffn.w_1.bias");
-      if (L.w1_b3 != NO_B3) {  // the SAME packed fp32 values, split exactly into three bf16 planes
-        const size_t n = (size_t)c.d_inner * c.ffn_k1 * d;
-        unsigned short* pl = reinterpret_cast<unsigned short*>(&img[L.w1_b3]);
-        split_weights_b3(&img[L.w1], n, pl, pl + n, pl + 2 * n);
-      }
-      pack_conv(S(p + ".pos_ffn.w_2.weight"), d, c.d_inner, c.ffn_k2, &img[L.w2]); cp(L.w2_b, p + ".pos_ffn.w_2.bias");
       cp(L.ln2_g, p + ".pos_ffn.layer_norm.weight"); cp(L.ln2_b, p + ".pos_ffn.layer_norm.bias");
+      pack_conv(S(p + ".pos_ffn.w_2.weight"), d, c.d_inner, c.ffn_k2, &img[L.w2]); cp(L.w2_b, p + ".pos_ffn.w_2.bias");
+      // opt-in bf16x3 mode: the SAME packed fp32 values, split exactly into three bf16 planes
+      auto split = [&](size_t src, size_t dst, size_t n) {
+        if (dst == NO_B3) return;
+        unsigned short* pl = reinterpret_cast<unsigned short*>(&img[dst]);
+        split_weights_b3(&img[src], n, pl, pl + n, pl + 2 * n);
+      };
+      split(L.qkv_w, L.qkv_b3, (size_t)3 * d * d);
+      split(L.fc_w, L.fc_b3, (size_t)d * d);
+      split(L.w1, L.w1_b3, (size_t)c.d_inner * c.ffn_k1 * d);
+      split(L.w2, L.w2_b3, (size_t)d * c.ffn_k2 * c.d_inner);
     }
   };
   do_stack("txt_encoder", m->enc, c.d_enc);
@@ -401,7 +412,7 @@ static int gemm(const float* X, int ldx, const float* W, const float* bias, cons
   p.epi = epi ? epi_mode : EPI_NONE;
   if (epi) p.e = *epi;
   // opt-in bf16x3 planes exist for this weight AND the launch is large enough for the 128-row tiles: split-bf16 matrix cores
-  if (Wb3 && !epi && conv_gemm_b3_ok(M, N, Cin, KW)) {
+  if (Wb3 && conv_gemm_b3_ok(M, N, Cin, KW, p.epi)) {
     p.Wb3 = Wb3;
     NS_HIP(launch_conv_gemm_b3(p, st));
     return 0;
@@ -421,12 +432,12 @@ static bool fuse_row_epilogue(int M, int N, int Cin) {
 // Y = mask(LayerNorm(act(conv(X)) + resid)): one launch when the full-row tile applies, else GEMM -> tmp -> k_layernorm
 static int gemm_ln(const float* X, int ldx, const float* W, const float* bias, const float* resid, float* tmp, float* Y,
                    int M, int N, int Cin, int KW, int S, int act, const float* g, const float* b, const long long* lens,
-                   hipStream_t st) {
+                   hipStream_t st, const unsigned short* Wb3 = nullptr) {
   if (fuse_row_epilogue(M, N, Cin)) {
     RowEpilogue e;
     memset(&e, 0, sizeof(e));
     e.ln_g = g; e.ln_b = b; e.lens = lens;
-    return gemm(X, ldx, W, bias, resid, N, Y, N, M, N, Cin, KW, S, act, st, &e, EPI_LN);
+    return gemm(X, ldx, W, bias, resid, N, Y, N, M, N, Cin, KW, S, act, st, &e, EPI_LN, Wb3);
   }
   NS_TRY(gemm(X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st));
   NS_HIP(launch_layernorm(tmp, g, b, Y, M, N, S, lens, st));
@@ -465,7 +476,8 @@ struct ProfScope {
 static int mha(const ns_model* m, const LayerW& L, int d, int H, const float* x, const long long* lens, int B, int S,
                float* out, bool mask_rows, Scratch& sc, hipStream_t st) {
   const int M = B * S;
-  NS_TRY(gemm(x, d, m->P(L.qkv_w), m->P(L.qkv_b), nullptr, 0, sc.qkv, 3 * d, M, 3 * d, d, 1, S, ACT_NONE, st));
+  auto b3 = [&](size_t off) { return off != NO_B3 ? reinterpret_cast<const unsigned short*>(m->P(off)) : nullptr; };
+  NS_TRY(gemm(x, d, m->P(L.qkv_w), m->P(L.qkv_b), nullptr, 0, sc.qkv, 3 * d, M, 3 * d, d, 1, S, ACT_NONE, st, nullptr, EPI_NONE, b3(L.qkv_b3)));
   {
     ProfScope ps(m, 1, st, 4.0 * (double)M * (double)S * (double)d);
     NS_TRY(ps.begin());
@@ -473,7 +485,7 @@ static int mha(const ns_model* m, const LayerW& L, int d, int H, const float* x,
     NS_TRY(ps.end());
   }
   return gemm_ln(sc.att, d, m->P(L.fc_w), m->P(L.fc_b), x, sc.t1, out, M, d, d, 1, S, ACT_NONE, m->P(L.ln1_g), m->P(L.ln1_b),
-                 mask_rows ? lens : nullptr, st);
+                 mask_rows ? lens : nullptr, st, b3(L.fc_b3));
 }
 
 // PositionwiseFeedForward.forward (transformer/SubLayers.py:87-95)
@@ -489,7 +501,8 @@ static int ffn(const ns_model* m, const LayerW& L, int d, const float* x, const 
     NS_TRY(ps.end());
   }
   return gemm_ln(sc.hid, c.d_inner, m->P(L.w2), m->P(L.w2_b), x, sc.t1, out, M, d, c.d_inner, c.ffn_k2, S, ACT_NONE, m->P(L.ln2_g),
-                 m->P(L.ln2_b), mask_rows ? lens : nullptr, st);
+                 m->P(L.ln2_b), mask_rows ? lens : nullptr, st,
+                 L.w2_b3 != NO_B3 ? reinterpret_cast<const unsigned short*>(m->P(L.w2_b3)) : nullptr);
 }
 
 // FFTBlock.forward (transformer/Layers.py:39-48): both masked_fill's are fused into the LayerNorm kernels

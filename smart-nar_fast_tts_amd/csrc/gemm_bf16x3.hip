@@ -21,7 +21,7 @@
 // clocks down to ~1.7 GHz under it (fp32 MFMA kernel: 87 % busy at ~2.1 GHz in the same run) — power, not issue, bound.
 #include <cstring>
 
-#include "kernels.h"
+#include "rowln.h"
 
 namespace ns {
 
@@ -43,7 +43,7 @@ __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, uns
 // two bf16 (given as fp32 bit patterns with zero low halves) -> one dword, element 0 in the low half
 __device__ __forceinline__ unsigned pack2(unsigned e0, unsigned e1) { return __builtin_amdgcn_perm(e1, e0, 0x07060302u); }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool ROWEPI = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gemm_b3(ConvGemm p, int ntn) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BK = 32, NW = WGM * WGN;
@@ -52,6 +52,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gemm_b3(ConvGemm p, int
   constexpr int TOTA = BM / 8;   // DMA instructions per A chunk (8 rows of 128 B each)
   constexpr int TOTB = BN / 16;  // per weight plane (16 rows of 64 B each)
   static_assert(TOTA % NW == 0 && TOTB % NW == 0, "DMA work divides evenly over the waves (no branch around a DMA)");
+  static_assert(!ROWEPI || (BM <= 64 && BN % 256 == 0 && BM % NW == 0 && 32 * BN * 4 <= 3 * BN * BK * 2),
+                "row epilogue: the BM x BN fp32 tile is parked 32 rows per weight-plane buffer");
   constexpr int IA = TOTA / NW, IB = TOTB / NW;
 
   __shared__ __attribute__((aligned(16))) float As0[BM * BK];
@@ -190,35 +192,83 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gemm_b3(ConvGemm p, int
 
   // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); bias / act / residual as gemm_conv.hip
   const int ecol = lane & 31, erow = (lane >> 5) * 4;
+  if constexpr (ROWEPI) {
+    // full-row tile (BN == N): the same row epilogue as gemm_conv.hip's (rowln.h) — LayerNorm (+ mask) of act(acc + bias) +
+    // residual, one row per wave64; rows [0,32) of the tile are parked in Bs0, [32,64) in Bs1
+    auto trow = [&](int ml) -> float* { return reinterpret_cast<float*>(ml < 32 ? Bs0 : Bs1) + (ml & 31) * BN; };
 #pragma unroll
-  for (int ni = 0; ni < TN; ++ni) {
-    const int n = n0 + wn0 + ni * 32 + ecol;
-    if (n >= p.N) continue;
-    const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int ni = 0; ni < TN; ++ni) {
+      const int nl = wn0 + ni * 32 + ecol;
+      const float bv = p.bias ? p.bias[n0 + nl] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + erow;
-      if (m >= p.M) continue;
-      float v = acc[ni][r] + bv;
-      if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
-      else if (p.act == ACT_TANH) v = tanhf(v);
-      if (p.resid) v += p.resid[(size_t)m * p.ldr + n];
-      p.Y[(size_t)m * p.ldy + n] = v;
+      for (int r = 0; r < 16; ++r) {
+        const int ml = wm0 + (r & 3) + 8 * (r >> 2) + erow;
+        float v = acc[ni][r] + bv;
+        if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (p.act == ACT_TANH) v = tanhf(v);
+        trow(ml)[nl] = v;
+      }
+    }
+    __syncthreads();
+    constexpr int NV = BN / 256, RPW = BM / NW;
+#pragma unroll 1
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int ml = wid * RPW + rr, m = m0 + ml;
+      if (m >= p.M) break;
+      const int b = m / p.S, t = m - b * p.S;
+      const bool masked = p.e.lens && (long long)t >= p.e.lens[b];
+      if (masked) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + lane * 4 + i * 256) = f32x4{0.f, 0.f, 0.f, 0.f};
+        continue;
+      }
+      f32x4 v[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(trow(ml) + lane * 4 + i * 256);
+        if (p.resid) v[i] += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + lane * 4 + i * 256);
+      }
+      float mean, rstd;
+      ln_moments<NV>(v, BN, lane, mean, rstd);
+      ln_store<NV>(v, BN, lane, mean, rstd, p.e.ln_g, p.e.ln_b, p.Y + (size_t)m * p.ldy);
+    }
+  } else {
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int n = n0 + wn0 + ni * 32 + ecol;
+      if (n >= p.N) continue;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + erow;
+        if (m >= p.M) continue;
+        float v = acc[ni][r] + bv;
+        if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (p.act == ACT_TANH) v = tanhf(v);
+        if (p.resid) v += p.resid[(size_t)m * p.ldr + n];
+        p.Y[(size_t)m * p.ldy + n] = v;
+      }
     }
   }
 #endif
 }
 
-bool conv_gemm_b3_ok(int M, int N, int Cin, int KW) {
-  // needs enough 128-row tiles to fill the chip with one workgroup per CU, and descriptor offsets inside 31 bits
-  return Cin % 32 == 0 && N % 16 == 0 && (long long)((M + 127) / 128) * ((N + 255) / 256) >= 200 &&
-         3ll * N * KW * Cin * 2 < (1ll << 31);
+bool conv_gemm_b3_ok(int M, int N, int Cin, int KW, int epi) {
+  if (Cin % 32 != 0 || N % 16 != 0 || 3ll * N * KW * Cin * 2 >= (1ll << 31)) return false;
+  // LayerNorm epilogue: the 64 x 256 full-row tile, one workgroup per CU; plain: 128-row tiles, enough of them to fill the chip
+  if (epi == EPI_LN) return N == 256 && (M + 63) / 64 >= 200;
+  return epi == EPI_NONE && (long long)((M + 127) / 128) * ((N + 255) / 256) >= 200;
 }
 
 hipError_t launch_conv_gemm_b3(const ConvGemm& p, hipStream_t st) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
-  if (!p.Wb3 || !conv_gemm_b3_ok(p.M, p.N, p.Cin, p.KW) || (p.ldx & 3) || p.epi != EPI_NONE) return hipErrorInvalidValue;
-  if ((long long)(128 + p.KW) * p.ldx >= (1ll << 29)) return hipErrorInvalidValue;
+  if (!p.Wb3 || !conv_gemm_b3_ok(p.M, p.N, p.Cin, p.KW, p.epi) || (p.ldx & 3)) return hipErrorInvalidValue;
+  if ((long long)(256 + p.KW) * p.ldx >= (1ll << 29)) return hipErrorInvalidValue;
+  if (p.epi == EPI_LN) {
+    if ((p.ldy & 3) || (p.resid && (p.ldr & 3))) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_conv_gemm_b3<64, 256, 2, 4, true>), dim3((p.M + 63) / 64), dim3(512), 0, st, p, 1);
+    return hipGetLastError();
+  }
   const int ntn = (p.N + 255) / 256;
   // 256-row tiles halve the weight-plane traffic per flop (k=9 decoder GEMM: 324 vs 355 us) but need a workgroup per CU
   const int ntm256 = (p.M + 255) / 256, ntm128 = (p.M + 127) / 128;

@@ -40,7 +40,7 @@ struct ConvGemm {
 };
 hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st);
 // opt-in "bf16x3" precision mode (gemm_bf16x3.hip): same contraction from an exact 3-way bf16 split of both operands
-bool conv_gemm_b3_ok(int M, int N, int Cin, int KW);
+bool conv_gemm_b3_ok(int M, int N, int Cin, int KW, int epi);  // epi: EPI_NONE or EPI_LN
 hipError_t launch_conv_gemm_b3(const ConvGemm& p, hipStream_t st);
 void split_weights_b3(const float* w, size_t n, unsigned short* hi, unsigned short* mid, unsigned short* lo);
 // true when launch_conv_gemm has a full-row tile for this shape (so p.epi may be set); otherwise the caller runs the

@@ -2,31 +2,44 @@
 # Collect one round's rocprofv3 evidence ON THE GPU BOX (run through gpurun), then summarise it here with
 # `python tools/make_profiles.py rNN`:
 #
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02'
 #
-# One kernel-trace pass plus one PMC pass per counter group (never combined with a trace domain other than
-# --kernel-trace; FETCH_SIZE and WRITE_SIZE in separate passes as MI355X_MICROARCH.md prescribes).
+# Per workload one kernel-trace pass; for config 2 and config 5 additionally one PMC pass per counter group (never
+# combined with a trace domain other than --kernel-trace; FETCH_SIZE and WRITE_SIZE in separate passes as
+# MI355X_MICROARCH.md prescribes).  bench.py runs with --no-extras under the profiler: the trace then holds exactly
+# (warmup + steps) forwards of the workload, nothing else.
 set -u
-R=${1:-r01}
+R=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 
 python "$ROOT/bench.py" > "$OUT/${R}_bench.log" 2>&1
 tail -1 "$OUT/${R}_bench.log" > "$OUT/${R}_bench.json"
 
-rocprofv3 --kernel-trace --stats --output-format rocpd csv -d "$OUT/${R}_trace" -o t -- $BENCH > "$OUT/${R}_trace.log" 2>&1
-grep '^{' "$OUT/${R}_trace.log" | tail -1 > "$OUT/${R}_bench_under_trace.json"
-# rocprofv3's own per-kernel summary, as it wrote it (committed next to the per-geometry table make_profiles.py derives)
+for WL in cfg2_b16 cfg1_single cfg4_d512 cfg5_longform; do
+  TAG=${R}_trace; [ "$WL" != cfg2_b16 ] && TAG=${R}_trace_${WL}
+  BENCH="python $ROOT/bench.py --workload $WL --steps 5 --warmup 2 --no-extras"
+  rocprofv3 --kernel-trace --stats --output-format rocpd csv -d "$OUT/$TAG" -o t -- $BENCH > "$OUT/$TAG.log" 2>&1
+  grep '^{' "$OUT/$TAG.log" | tail -1 > "$OUT/${TAG/_trace/_bench_under_trace}.json"
+done
+# rocprofv3's own per-kernel summary of the config-2 run, as it wrote it
 find "$OUT/${R}_trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/${R}_rocprofv3_kernel_stats.csv" \;
 
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/${R}_fetch" -o t -- $BENCH > "$OUT/${R}_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/${R}_write" -o t -- $BENCH > "$OUT/${R}_write.log" 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE \
-  -d "$OUT/${R}_mfma" -o t -- $BENCH > "$OUT/${R}_mfma.log" 2>&1
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY \
-  -d "$OUT/${R}_lds" -o t -- $BENCH > "$OUT/${R}_lds.log" 2>&1
-ls -la "$OUT"/${R}_*/ | head -40
-cat "$OUT/${R}_bench.json"
+for WL in cfg2_b16 cfg5_longform; do
+  SUF=""; [ "$WL" != cfg2_b16 ] && SUF=_${WL}
+  BENCH="python $ROOT/bench.py --workload $WL --steps 5 --warmup 2 --no-extras"
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/${R}_fetch$SUF" -o t -- $BENCH > "$OUT/${R}_fetch$SUF.log" 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/${R}_write$SUF" -o t -- $BENCH > "$OUT/${R}_write$SUF.log" 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE \
+    -d "$OUT/${R}_mfma$SUF" -o t -- $BENCH > "$OUT/${R}_mfma$SUF.log" 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY \
+    -d "$OUT/${R}_lds$SUF" -o t -- $BENCH > "$OUT/${R}_lds$SUF.log" 2>&1
+done
+# the opt-in bf16x3 mode, for the record (never the headline)
+python "$ROOT/bench.py" --matmul bf16x3 --no-cpu-baseline > "$OUT/${R}_bench_bf16x3.log" 2>&1
+tail -1 "$OUT/${R}_bench_bf16x3.log" > "$OUT/${R}_bench_bf16x3.json"
+rocprofv3 --kernel-trace --stats --output-format rocpd csv -d "$OUT/${R}_trace_bf16x3" -o t -- python $ROOT/bench.py --matmul bf16x3 --steps 5 --warmup 2 --no-extras > "$OUT/${R}_trace_bf16x3.log" 2>&1
+ls -d "$OUT"/${R}_*/ | head -40
+cat "$OUT/${R}_bench.json" | cut -c1-300

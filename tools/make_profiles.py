@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Turn one round's rocprofv3 outputs (gpurun_out/rNN_{trace,fetch,write,mfma,lds}/t_results.db + rNN_bench*.json)
-into the committed summaries under profiles/:
+"""Turn one round's rocprofv3 outputs (gpurun_out/rNN_{trace,fetch,write,mfma,lds}[_workload]/t_results.db +
+rNN_bench*.json, written by tools/collect_profiles.sh on the GPU box) into the committed summaries under profiles/:
 
-    python tools/make_profiles.py r01
+    python tools/make_profiles.py r02
 
 * profiles/rNN_kernel_stats.md          per-kernel stats of `rocprofv3 --kernel-trace --stats -- python bench.py ...`
 * profiles/rNN_pmc.md                   per-dispatch PMC averages (separate passes) for the hot kernels
@@ -45,7 +45,7 @@ under = json.load(open(f"{G}/{ROUND}_bench_under_trace.json"))
 # HIP-event average of the same launches in the same process.
 import sqlite3
 con = sqlite3.connect(f"{G}/{ROUND}_trace/t_results.db")
-rows = con.execute("select start, end, grid_x / workgroup_x as wgs from kernels where name like '%k_conv_gemm<64, 256, 32, 1, 2, 4>%' order by start").fetchall()
+rows = con.execute("select start, end, grid_x / workgroup_x as wgs from kernels where name like '%k_conv_gemm<64, 256, 32, 1, 2, 4%' order by start").fetchall()
 if rows:
     big = max(r[2] for r in rows)
     durs = [(r[1] - r[0]) / 1e3 for r in rows if r[2] == big]
@@ -58,7 +58,45 @@ if rows:
         fh.write(f"\nDominant kernel, timed region only (last {len(timed)} of {len(durs)} launches of the {int(big)}-workgroup "
                  f"`k_conv_gemm<64, 256, 32, 1, 2, 4>`): rocprofv3 avg {sum(timed) / len(timed):.1f} us; bench.py's HIP events "
                  f"around the same launches in the same process: {under['roofline']['avg_launch_ms'] * 1e3:.1f} us.\n")
+
+
+def launches_per_forward(db):
+    """kernel dispatches between two consecutive k_embed_pos launches (= one forward; the device-to-host copy of
+    mel_lens is a blit kernel and is counted), from the last complete forward of the trace"""
+    c = sqlite3.connect(db)
+    names = [r[0] for r in c.execute("select name from kernels order by start").fetchall()]
+    idx = [i for i, n in enumerate(names) if "k_embed_pos" in n]
+    if len(idx) < 2:
+        return None
+    seg = names[idx[-2]:idx[-1]]
+    return len(seg), sum(1 for n in seg if "rocclr" in n)
+
+
+lp = launches_per_forward(f"{G}/{ROUND}_trace/t_results.db")
+if lp:
+    with open(f"profiles/{ROUND}_kernel_stats.md", "a") as fh:
+        fh.write(f"\nLaunches per config-2 forward (dispatches from one `k_embed_pos` to the next, bench.py --no-extras under the "
+                 f"trace): **{lp[0]}** ({lp[0] - lp[1]} kernels of the library + {lp[1]} runtime copy kernel for the mel_lens read).\n")
+    under["launches_per_forward"] = lp[0]
 json.dump({"bench": bench, "bench_under_kernel_trace": under}, open(f"profiles/{ROUND}_bench.json", "w"), indent=1)
+
+# the other BASELINE configs (kernel trace only) and the opt-in bf16x3 mode
+for wl in ("cfg1_single", "cfg4_d512", "cfg5_longform", "bf16x3"):
+    db = f"{G}/{ROUND}_trace_{wl}/t_results.db"
+    if not os.path.exists(db):
+        continue
+    txt = run("tools/rocpd_stats.py", db)
+    lpw = launches_per_forward(db)
+    if lpw:
+        txt += f"\nLaunches per forward: {lpw[0]} (incl. {lpw[1]} runtime copy kernel).\n"
+    ub = f"{G}/{ROUND}_bench_under_trace_{wl}.json"
+    if os.path.exists(ub) and os.path.getsize(ub) > 2:
+        u = json.load(open(ub))
+        txt += (f"\nbench.py under this trace: {u['value']:.0f} frames/s, {u['ms_per_step']:.3f} ms/step, dominant kernel "
+                f"{u['roofline']['achieved']} TFLOP/s ({u['config']['workload'][:60]})\n")
+    open(f"profiles/{ROUND}_kernel_stats_{wl}.md", "w").write(txt)
+if os.path.exists(f"{G}/{ROUND}_bench_bf16x3.json") and os.path.getsize(f"{G}/{ROUND}_bench_bf16x3.json") > 2:
+    shutil.copy(f"{G}/{ROUND}_bench_bf16x3.json", f"profiles/{ROUND}_bench_bf16x3.json")
 
 # the dominant kernel = the most expensive (kernel, grid) of the trace
 f = pmc_rows(f"{G}/{ROUND}_fetch/t_results.db")
@@ -89,14 +127,40 @@ d = {
 }
 json.dump(d, open("profiles/dominant_kernel_traffic.json", "w"), indent=1)
 
+# fused attention of the decoder stack: FETCH / WRITE per launch against its algorithmic bytes (Q, K, V read once, O written
+# once = 4 * rows * d * 4 B), configs 2 and 5
+att = {}
+for suf, label in (("", "cfg2_b16"), ("_cfg5_longform", "cfg5_longform")):
+    fdb, wdb = f"{G}/{ROUND}_fetch{suf}/t_results.db", f"{G}/{ROUND}_write{suf}/t_results.db"
+    if not (os.path.exists(fdb) and os.path.exists(wdb)):
+        continue
+    fa, wa = pmc_rows(fdb), pmc_rows(wdb)
+    ks = [k for k in fa if "k_attention<" in k[0] and k[2] == "FETCH_SIZE"]
+    if not ks:
+        continue
+    k = max(ks, key=lambda k: fa[k][1] * fa[k][2])  # the decoder launches (longest total time)
+    ub = f"{G}/{ROUND}_bench_under_trace{suf}.json"
+    u = json.load(open(ub)) if os.path.exists(ub) and os.path.getsize(ub) > 2 else bench
+    T = int(re.search(r"T_pad (\d+)", u["config"]["workload"]).group(1))
+    rows_a = u["config"]["global_batch"] * T
+    att[label] = {"kernel": k[0], "rows": rows_a, "T_pad": T, "avg_duration_us_under_pmc": round(fa[k][1], 1),
+                  "fetch_bytes_corrected_x2": fa[k][0] * 2048, "write_bytes": wa[(k[0], k[1], "WRITE_SIZE")][0] * 1024,
+                  "algorithmic_bytes_per_launch": 4 * rows_a * 256 * 4}
+    att[label]["hbm_bytes_per_launch"] = att[label]["fetch_bytes_corrected_x2"] + att[label]["write_bytes"]
+    att[label]["traffic_over_algorithmic"] = round(att[label]["hbm_bytes_per_launch"] / att[label]["algorithmic_bytes_per_launch"], 2)
+if att:
+    json.dump(att, open(f"profiles/{ROUND}_attention_traffic.json", "w"), indent=1)
+
 with open(f"profiles/{ROUND}_pmc.md", "w") as fh:
     fh.write(f"# PMC passes for {ROUND} (rocprofv3 --pmc, one counter group per pass; per-dispatch averages, hot kernels only)\n")
-    for tag in ("fetch", "write", "mfma", "lds"):
+    for tag in ("fetch", "write", "mfma", "lds", "fetch_cfg5_longform", "write_cfg5_longform", "mfma_cfg5_longform", "lds_cfg5_longform"):
+        if not os.path.exists(f"{G}/{ROUND}_{tag}/t_results.db"):
+            continue
         out = run("tools/rocpd_pmc.py", f"{G}/{ROUND}_{tag}/t_results.db").splitlines()
         keep = [l for l in out if l.startswith("| kernel") or l.startswith("|---")]
         body = [l for l in out if l.startswith("| `")]
         # hot kernels of the benchmark workload: large grids only
-        body = [l for l in body if int(l.split("|")[2]) >= 250]
+        body = [l for l in body if int(l.split("|")[2]) >= 250 or "k_attention<" in l]
         fh.write(f"\n## pass: {tag}\n\n" + "\n".join(keep + body[:40]) + "\n")
 print(json.dumps(d, indent=1))
 print(bench["ms_per_step"], bench["value"], bench["roofline"])
