@@ -324,7 +324,7 @@ def main():
         # pick different pitch/energy buckets for values that sit on a bucket edge (fp32 summation order);
         # with the oracle's pitch/energy handed to the HIP path as p_targets/e_targets the discrete choices are pinned.
         # What the figures mean: durations / frame counts must be identical.  Free-running, any fp32 evaluation other than
-        # torch-CPU's may legally pick the neighbouring embedding row for a value within EDGE_REL (1e-5 relative) of a bin
+        # torch-CPU's may legally pick the neighbouring embedding row for a value within EDGE_REL (2e-5 relative) of a bin
         # edge (model/modules.py:86-88,97-99); one such flip changes every frame of its utterance through global attention,
         # which is what postnet_max_abs_free_running shows.  bucket_flips counts them, bucket_flips_off_edge counts flips
         # that are NOT at an edge (must be 0: that would be a real error), and the pinned run is the parity number.

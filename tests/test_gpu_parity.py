@@ -47,7 +47,7 @@ def run_gpu(m, z, meta, texts_key="texts", p_targets=None, e_targets=None):
     return out
 
 
-EDGE_REL = 1e-5  # tests/golden/make_golden.py PE_MARGIN: relative distance to a bucket edge below which a flip is fp32 noise
+from oracle.parity import EDGE_REL  # noqa: E402  relative distance to a bucket edge below which a flip is fp32 noise (2e-5)
 
 
 def bucket_flips(sd, out, z, which="pe", what="free run"):
