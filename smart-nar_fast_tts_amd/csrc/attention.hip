@@ -55,13 +55,30 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   __shared__ __attribute__((aligned(16))) float Vs0[BC * DK];
   __shared__ __attribute__((aligned(16))) float Vs1[BC * DK];
 
-  const int b = blockIdx.z, hd = blockIdx.y;
+  // XCD-aware bijective remap (workgroup L runs on XCD L % 8: observed, used for speed only).  In launch order the query
+  // tiles of one (batch, head) are consecutive workgroups, i.e. they land on 8 DIFFERENT XCDs and every XCD pulls that
+  // head's K and V through its own L2 (profiles/r02: 4.5x the algorithmic bytes at config 2).  Handing XCD x the x-th
+  // contiguous slice of the (batch, head, query tile) order instead keeps all query tiles of a head on one L2.
+#if defined(NS_LAB_ATT_NOREMAP)
+  const int bx = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+#else
+  int bx, hd, b;
+  {
+    const int nx = gridDim.x, ny = gridDim.y, nblk = nx * ny * gridDim.z;
+    const int L = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = L & 7;
+    const int pos = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (L >> 3);
+    bx = pos % nx;
+    hd = (pos / nx) % ny;
+    b = pos / (nx * ny);
+  }
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, qi = lane & 31;
   // nsplit > 1 (few workgroups, long key axis): workgroup (qt, sp) sweeps only the sp-th contiguous share of the key
   // tiles and leaves an un-normalised partial (O^T, m, l) for k_attention_merge; softmax is exact per part
-  const int qt = blockIdx.x / nsplit, sp = blockIdx.x - qt * nsplit;
+  const int qt = bx / nsplit, sp = bx - qt * nsplit;
   const int q = qt * 128 + wid * 32 + qi;
   const int ld = 3 * d;
   const float* base = qkv + (size_t)b * S * ld + hd * DK;
