@@ -79,6 +79,8 @@ size_t ns_decoder_ws_bytes(const ns_model* m, int B, int L, int T);
 /* Phase 1: get_mask_from_lengths + TxtEncoder + duration predictor + rounding + duration scan.
  * Writes log_d [B,L], d_rounded [B,L] (float32, may hold -0.0), src_mask [B,L], mel_lens [B] (int64).
  * The encoder output and the duration prefix sums stay in ws_enc for phase 2.
+ * mel_lens_host (nullable): device-visible HOST memory (hipHostMalloc / a pinned torch tensor), [B] int64; the kernel that
+ * produces mel_lens writes a second copy there, so the caller's read needs only a stream synchronisation, no D2H copy.
  * A token id outside [0, n_vocab) (nn.Embedding raises IndexError, transformer/Models.py:89) is reported as
  * mel_lens[b] = -1 for its utterance; the kernels read embedding row 0 for it, nothing out of bounds.
  * The caller reads mel_lens back (the one unavoidable device->host read: the output tensors are
@@ -90,7 +92,7 @@ int ns_forward_durations(ns_model* m, const int64_t* texts, const int64_t* src_l
                          float d_control, float p_control, float e_control, const float* p_targets, const float* e_targets,
                          void* ws_enc, size_t ws_enc_bytes,
                          float* log_d, float* d_rounded, uint8_t* src_mask, int64_t* mel_lens, float* p_pred, float* e_pred,
-                         void* stream);
+                         int64_t* mel_lens_host, void* stream);
 
 /* Phase 2: LengthRegulator + frame-level pitch/energy + MelDecoder + mel_linear + PostNet (+ residual).
  * T must be max(mel_lens) (or a caller-chosen max_mel_len >= it, model/modules.py:128-129 semantics).

@@ -38,7 +38,7 @@ SIGNATURES = {
     "ns_adopt_arena": (_I, [_P]),
     "ns_encoder_ws_bytes": (_Z, [_P, _I, _I]),
     "ns_decoder_ws_bytes": (_Z, [_P, _I, _I, _I]),
-    "ns_forward_durations": (_I, [_P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _P]),
+    "ns_forward_durations": (_I, [_P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ns_forward_mel": (_I, [_P, _I, _I, _I, _P, _F, _F, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P]),
     "ns_op_ws_bytes": (_Z, [_P, _I, _I]),
     "ns_op_mask_from_lengths": (_I, [_P, _I, _I, _P, _P]),

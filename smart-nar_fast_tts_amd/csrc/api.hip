@@ -609,7 +609,7 @@ static int decoder_stack(const ns_model* m, float* x, const long long* lens, int
 extern "C" int ns_forward_durations(ns_model* m, const int64_t* texts, const int64_t* src_lens, int B, int L, float d_control,
                                     float p_control, float e_control, const float* p_targets, const float* e_targets,
                                     void* ws_enc, size_t ws_bytes, float* log_d, float* d_rounded, uint8_t* src_mask,
-                                    int64_t* mel_lens, float* p_pred, float* e_pred, void* stream) {
+                                    int64_t* mel_lens, float* p_pred, float* e_pred, int64_t* mel_lens_host, void* stream) {
   NS_TRY(check_ready(m));
   if (B <= 0 || L <= 0) return fail("ns_forward_durations: empty batch");
   if (ws_bytes < ns_encoder_ws_bytes(m, B, L)) return fail("ns_forward_durations: workspace too small");
@@ -638,7 +638,7 @@ extern "C" int ns_forward_durations(ns_model* m, const int64_t* texts, const int
   // src mask (utils/tools.py:89-97), duration rounding (model/modules.py:132-135), repeat counts + prefix sums + mel_len
   // (:209-223): one launch
   NS_HIP(launch_duration_tail(log_d, lens, (const long long*)texts, c.n_vocab, B, L, d_control, d_rounded, dur_keep, cum,
-                              (long long*)mel_lens, src_mask, st));
+                              (long long*)mel_lens, src_mask, (long long*)mel_lens_host, st));
   return 0;
 }
 

@@ -310,9 +310,7 @@ hipError_t launch_attention(const float* qkv, const long long* lens, int B, int 
   int nsplit = 1;
   const long blocks = (long)qtiles * H * B;
   const size_t M = (size_t)B * S;
-  // (a short key axis is only worth splitting when the launch is nearly empty: at 16 x 128 keys — the encoder of a
-  // 16-utterance batch, 32 workgroups of 4 key tiles — the partial-store + merge launch costs what the split saves)
-  if (scratch && blocks < ATT_SPLIT_MAX_BLOCKS && (S >= 256 || blocks < 16)) {
+  if (scratch && blocks < ATT_SPLIT_MAX_BLOCKS) {
     nsplit = (int)(256 / blocks);
     if (nsplit > ATT_SPLIT_MAX) nsplit = ATT_SPLIT_MAX;
     if (nsplit > (S + 31) / 32) nsplit = (S + 31) / 32;  // at least one 32-key tile each

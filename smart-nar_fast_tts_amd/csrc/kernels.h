@@ -83,7 +83,7 @@ hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int
 // holds a token id outside [0, n_vocab) (texts may be nullptr: no check)
 hipError_t launch_duration_tail(const float* log_d, const long long* src_lens, const long long* texts, int n_vocab, int B, int L,
                                 float d_control, float* d_rounded, float* d_keep, int32_t* cum, long long* mel_lens, uint8_t* src_mask,
-                                hipStream_t st);
+                                long long* mel_lens_host /* nullable: device-visible host copy */, hipStream_t st);
 hipError_t launch_gaussian_upsampling(const float* x, const float* dur, int B, int L, int D, int T, int T_out,
                                       float* out, float* s, float* w, const long long* own_len, hipStream_t st);
 

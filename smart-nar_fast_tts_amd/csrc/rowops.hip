@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_duration_scan(const float* __restrict__
                                                         long long* __restrict__ mel_lens, const long long* __restrict__ src_lens,
                                                         float d_control, float* __restrict__ d_rounded, float* __restrict__ d_keep,
                                                         uint8_t* __restrict__ src_mask, const long long* __restrict__ texts,
-                                                        int n_vocab) {
+                                                        int n_vocab, long long* __restrict__ mel_lens_host) {
   __shared__ int wsum[4];
   __shared__ int carry_s;
   __shared__ int bad_s;
@@ -251,20 +251,26 @@ __global__ __launch_bounds__(256) void k_duration_scan(const float* __restrict__
     if (tid == 255) carry_s = inc + off;
     __syncthreads();
   }
-  if (tid == 0) mel_lens[b] = bad_s ? -1ll : (long long)carry_s;
+  if (tid == 0) {
+    const long long n = bad_s ? -1ll : (long long)carry_s;
+    mel_lens[b] = n;
+    // optional second copy straight into device-visible (pinned) HOST memory: the caller's one read of mel_lens then needs
+    // a stream synchronisation only, no device-to-host copy behind the kernel
+    if (mel_lens_host) mel_lens_host[b] = n;
+  }
 }
 hipError_t launch_duration_scan(const float* d_rounded, int B, int L, int32_t* cum, long long* mel_lens, hipStream_t st) {
   if (B <= 0) return hipSuccess;
   hipLaunchKernelGGL((k_duration_scan<false>), dim3(B), dim3(256), 0, st, d_rounded, L, cum, mel_lens, nullptr, 1.0f, nullptr, nullptr,
-                     nullptr, nullptr, 0);
+                     nullptr, nullptr, 0, nullptr);
   return hipGetLastError();
 }
 hipError_t launch_duration_tail(const float* log_d, const long long* src_lens, const long long* texts, int n_vocab, int B, int L,
                                 float d_control, float* d_rounded, float* d_keep, int32_t* cum, long long* mel_lens, uint8_t* src_mask,
-                                hipStream_t st) {
+                                long long* mel_lens_host, hipStream_t st) {
   if (B <= 0) return hipSuccess;
   hipLaunchKernelGGL((k_duration_scan<true>), dim3(B), dim3(256), 0, st, log_d, L, cum, mel_lens, src_lens, d_control, d_rounded, d_keep,
-                     src_mask, texts, n_vocab);
+                     src_mask, texts, n_vocab, mel_lens_host);
   return hipGetLastError();
 }
 

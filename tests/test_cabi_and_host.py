@@ -89,7 +89,7 @@ def test_forward_refuses_without_weights(lib):
     h = C.c_void_p()
     assert so.ns_create(C.byref(_cfg(L)), C.byref(h)) == 0
     rc = so.ns_forward_durations(h, None, None, 1, 4, 1.0, 1.0, 1.0, None, None, None, 0, None, None, None, None, None, None,
-                                 None)
+                                 None, None)
     assert rc != 0 and "weights not loaded" in so.ns_last_error().decode()
     so.ns_destroy(h)
 
@@ -211,7 +211,7 @@ def test_workspace_cache_is_bounded():
 
     from smart_nar_fast_tts_amd.model import FastSpeech2Align
 
-    cap = 2 * FastSpeech2Align.MAX_WORKSPACE_STREAMS
+    cap = 3 * FastSpeech2Align.MAX_WORKSPACE_STREAMS  # enc + dec scratch + the pinned mel_lens buffer per stream
     ws = OrderedDict()
     for i in range(50):  # what _workspace does per call, without a device
         ws[("enc", i)] = i
