@@ -339,6 +339,12 @@ hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) {
   // TFLOP/s on the dominant shape; 2x4 grids: 139-141.)
   const long rows64 = (p.M + 63) / 64, rows32 = (p.M + 31) / 32;
   auto wgs = [&](long rows, int bn) { return rows * ((p.N + bn - 1) / bn); };
+  // Narrow outputs (N = 80: mel_linear, the PostNet's last layer): three 32-column tiles instead of a 128-wide tile that
+  // is 37 % padding (tools/lab/gemm_lab_n80.hip: k5 512->80, M=16160 99.8 -> 85.2 us; M=64640 360 -> 310 us)
+  if (bk32 && p.N > 64 && p.N <= 96 && p.KW * p.Cin >= 1024) {
+    if (rows64 >= 512) return launch_t<64, 96, 32, 1, 2, 3>(p, st);
+    if (rows32 >= 400) return launch_t<32, 96, 32, 4, 1, 3>(p, st);
+  }
   if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400) return launch_t<64, 256, 32, 1, 2, 4>(p, st);
   if (bk32 && p.N >= 128 && wgs(rows64, 128) > 256) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
   // Fewer output tiles than that (encoder-side GEMMs, single-utterance latency): a workgroup's time is set by how fast
@@ -356,6 +362,9 @@ hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) {
     return launch_t<64, 64, 32>(p, st);
   }
   if (wgs(rows32, 32) <= 512) return launch_t<32, 32, 16, 4, 1, 1>(p, st);
+  // Cin = 80 (the PostNet's first layer): wider tiles once there are enough of them (M=16160 77 -> 73.5 us, M=64640 269 -> 250 us)
+  if (p.N >= 256 && wgs(rows64, 256) >= 1024) return launch_t<64, 256, 16, 1, 2, 4>(p, st);
+  if (p.N >= 128 && wgs(rows64, 128) >= 512) return launch_t<64, 128, 16, 1, 2, 4>(p, st);
   return launch_t<64, 64, 16>(p, st);
 }
 
