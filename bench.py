@@ -90,7 +90,9 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist, backend = None, None
-    if world > 1:
+    # NS_BENCH_FORCE_DIST=1 (test rigs): build the process group even for one rank, so that the RCCL code path (init,
+    # weight broadcast, all-reduce, all-gather) is exercised on a one-GPU box
+    if world > 1 or os.environ.get("NS_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -89,6 +89,28 @@ def test_bench_plain_command_launches_its_own_ranks():
         assert r.returncode != 0 and "no device" in (r.stdout + r.stderr)
 
 
+@pytest.mark.gpu
+def test_bench_one_rank_over_rccl():
+    """The N > 1 code path over the real backend ("nccl" = RCCL) with the one rank a test box can give it: process-group
+    init bound to the device, the weight-arena broadcast, the all-reduces of the timing block and the all-gather of the
+    device report, launched the way the driver launches N > 1 (torch.distributed.run, 127.0.0.1)."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    e = dict(os.environ, NS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    e.pop("NS_BENCH_ONE_GPU", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-extras"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=e)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d["backend"] == "nccl" and d["world_size_seen_by_rccl"] == 1 and d["one_gpu_rig"] is False
+    assert d["devices"] == [{"rank": 0, "device": "cuda:0", "name": d["devices"][0]["name"]}] and d["value"] > 0
+
+
 def test_self_launch_command_line(monkeypatch):
     """CPU: the re-exec command is the driver's own torchrun form (one node, N ranks, 127.0.0.1 rendezvous)."""
     import importlib.util
