@@ -79,6 +79,9 @@ int main(int argc, char** argv) {
       CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(db)); CK(hipFree(dy));
       continue;
     }
+    run<128, 64, 32, 1, 4, 2>(p, gf);
+    run<128, 128, 32, 1, 4, 2>(p, gf);
+    run<64, 64, 32, 2, 2, 2>(p, gf);
     run<32, 64, 32, 2, 1, 2>(p, gf);
     run<32, 64, 32, 1, 1, 2>(p, gf);
     run<32, 32, 32, 2, 1, 1>(p, gf);
