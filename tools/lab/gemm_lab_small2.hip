@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #define NS_LAB 1
 #include "gemm_conv.hip"
@@ -58,7 +59,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dx, nx * 4)); CK(hipMalloc(&dw, nw * 4)); CK(hipMalloc(&db, s.N * 4)); CK(hipMalloc(&dy, ny * 4));
     CK(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, hb.data(), s.N * 4, hipMemcpyHostToDevice));
-    ConvGemm p; p.X = dx; p.ldx = s.Cin; p.W = dw; p.bias = db; p.resid = nullptr; p.ldr = 0; p.Y = dy; p.ldy = s.N;
+    ConvGemm p; memset(&p, 0, sizeof(p)); p.X = dx; p.ldx = s.Cin; p.W = dw; p.bias = db; p.resid = nullptr; p.ldr = 0; p.Y = dy; p.ldy = s.N;
     p.M = s.M; p.N = s.N; p.Cin = s.Cin; p.KW = s.KW; p.pad = (s.KW - 1) / 2; p.S = s.S; p.act = ACT_RELU;
     double gf = 2.0 * s.M * s.Cin * s.KW * s.N / 1e9;
     printf("%s  %.1f GFLOP\n", s.name, gf);
