@@ -164,3 +164,8 @@ with open(f"profiles/{ROUND}_pmc.md", "w") as fh:
         fh.write(f"\n## pass: {tag}\n\n" + "\n".join(keep + body[:40]) + "\n")
 print(json.dumps(d, indent=1))
 print(bench["ms_per_step"], bench["value"], bench["roofline"])
+
+# per-launch roofline tables (every kernel of one forward, matched to its operation and flops)
+for wl in ("", "cfg1_single", "cfg4_d512", "cfg5_longform"):
+    if os.path.exists(f"{G}/{ROUND}_trace{'_' + wl if wl else ''}/t_results.db"):
+        subprocess.run(["python", "tools/roofline_table.py", ROUND] + ([wl] if wl else []))
