@@ -1,0 +1,454 @@
+// LAB ONLY (measured, not adopted — see README.md): k_attention with the key-tile loop written out slice by slice and pinned
+// with sched_barrier(0) (K fragment / V row prefetch one slice ahead, softmax in the shadow of the score MFMAs, two score
+// accumulator chains, ONE barrier per tile).  Bit-exact vs fp64 like the shipped kernel, LDS waits 5.6e5 -> 6.5e4 per launch —
+// and the same duration in the forward (138.2 vs 138.2 us at config 2, 984 vs 979 us at config 5).
+// Build a lab binary against it:  hipcc ... -include attention_pipelined.hip is NOT needed: copy it over csrc/attention.hip.
+// Fused multi-head self attention on the gfx950 fp32 matrix cores — replaces
+// MultiHeadAttention's head split + ScaledDotProductAttention (transformer/SubLayers.py:42-54,
+// transformer/Modules.py:14-25): bmm -> /sqrt(d_k) -> masked_fill(-inf at padded KEYS) -> softmax -> bmm.
+// The (H*B, S, S) score matrix is never materialised and the attention probabilities (a dead output at
+// inference) are not produced.
+//
+// One workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 queries for the whole
+// key sweep and is alone on its SIMD (the problem offers about one 32-query wave per SIMD at config 2), so the
+// softmax VALU work is hidden INSIDE the wave: the loop is software-pipelined — while the matrix pipe runs
+// S(t+1)^T = K(t+1) Q^T, the VALU does the online softmax of tile t, then P(t) V(t) follows.
+// K/V tiles of 32 keys arrive by LDS-DMA (`buffer_load_dwordx4 ... lds`), K one tile ahead of V, two buffers each.
+//
+// The trick that removes every P re-layout: compute the TRANSPOSED score tile S^T = K Q^T
+// (A = K tile, B = Q^T held in registers for the whole kernel).  In the 32x32 C/D layout each lane then
+// holds, for ONE query (col = lane&31), 16 of the 32 keys: key(r,h) = (r&3) + 8*(r>>2) + 4*h.
+//   * the softmax row reduction is 16 in-lane values + one cross-half shuffle;
+//   * the online-softmax rescale of O^T (same column = same query) is lane-local;
+//   * for O^T += V^T P^T the B operand of MFMA step r is literally register p[r]: MFMA's k index is free to
+//     be permuted as long as A and B agree, so step r / lane-half h is *defined* to be key(r,h) and the
+//     A operand is V[key(r,h)][d], one conflict-free ds_read_b32 per MFMA.
+// The K tile's DMA image is lane-linear, so its ds_read_b128 fragment reads are de-conflicted by an XOR swizzle
+// on the source side (16-byte slot s of key row r holds chunk s ^ f(r)); V is read a row at a time and stays linear.
+// Keys >= lens[b] get -inf before the softmax; key tiles entirely past lens[b] contribute exact zeros and
+// are skipped; rows past S are zero-filled by the buffer descriptor's range check.  Padded QUERY rows are
+// computed like the reference does.  An utterance with lens[b] == 0 yields NaN rows (0 * inf), as the reference's
+// all -inf softmax does (SURVEY.md §8b "Errors").
+#include "kernels.h"
+
+namespace ns {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int DK>
+__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, const long long* __restrict__ lens,
+                                                    int S, int d, float c_scale, float* __restrict__ out, int nsplit,
+                                                    float* __restrict__ opart, float* __restrict__ mlpart) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BC = 32;                    // keys per tile
+  constexpr int CPR = DK / 4;               // 16-B chunks per tile row
+  constexpr int RPI = 64 / CPR;             // tile rows one wave-wide DMA instruction fills
+  constexpr int NI = (BC * CPR) / (64 * 4); // DMA instructions per wave per tile (4 waves share the tile)
+  constexpr int NG = DK / 8;                // k-groups of the QK^T contraction
+  constexpr int NDB = DK / 32;              // 32-wide d blocks of O^T
+  constexpr int FSH = (DK == 32) ? 1 : 0;   // swizzle: rows per 256-B bank row = 2 for 128-B rows, else 1
+  constexpr int FMSK = (DK == 32) ? 7 : 15;
+  static_assert(DK == 32 || DK == 64 || DK == 128, "d_k");
+  static_assert(NI >= 1 && RPI * CPR == 64, "tile/DMA geometry");
+
+  // four DISTINCT LDS objects + a 2x unrolled tile loop with static buffer roles: hipcc tracks in-flight LDS-DMA per
+  // LDS object, so reading K1/V0 does not wait for the DMA that is filling K0/V1 (see gemm_conv.hip)
+  __shared__ __attribute__((aligned(16))) float Ks0[BC * DK];
+  __shared__ __attribute__((aligned(16))) float Ks1[BC * DK];
+  __shared__ __attribute__((aligned(16))) float Vs0[BC * DK];
+  __shared__ __attribute__((aligned(16))) float Vs1[BC * DK];
+
+  // XCD-aware bijective remap (workgroup L runs on XCD L % 8: observed, used for speed only).  In launch order the query
+  // tiles of one (batch, head) are consecutive workgroups, i.e. they land on 8 DIFFERENT XCDs and every XCD pulls that
+  // head's K and V through its own L2 (profiles/r02: 4.5x the algorithmic bytes at config 2).  Handing XCD x the x-th
+  // contiguous slice of the (batch, head, query tile) order instead keeps all query tiles of a head on one L2.
+#if defined(NS_LAB_ATT_NOREMAP)
+  const int bx = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+#else
+  int bx, hd, b;
+  {
+    const int nx = gridDim.x, ny = gridDim.y, nblk = nx * ny * gridDim.z;
+    const int L = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = L & 7;
+    const int pos = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (L >> 3);
+    bx = pos % nx;
+    hd = (pos / nx) % ny;
+    b = pos / (nx * ny);
+  }
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, qi = lane & 31;
+  // nsplit > 1 (few workgroups, long key axis): workgroup (qt, sp) sweeps only the sp-th contiguous share of the key
+  // tiles and leaves an un-normalised partial (O^T, m, l) for k_attention_merge; softmax is exact per part
+  const int qt = bx / nsplit, sp = bx - qt * nsplit;
+  const int q = qt * 128 + wid * 32 + qi;
+  const int ld = 3 * d;
+  const float* base = qkv + (size_t)b * S * ld + hd * DK;
+  long long len_ll = lens ? lens[b] : (long long)S;
+  const int len = (int)(len_ll < S ? len_ll : S);
+  const int nkt_all = (len + BC - 1) / BC;
+  const int tps = (nkt_all + nsplit - 1) / nsplit;       // key tiles per split
+  const int t0 = sp * tps;                               // first key tile of this workgroup
+  const int nkt = max(0, min(nkt_all, t0 + tps) - t0);   // its number of key tiles (kt below is local: 0..nkt-1)
+
+  // descriptors over this (batch, head)'s K and V column blocks; rows >= S are out of range -> the DMA writes zeros
+  const int nrec = ((S - 1) * ld + DK) * 4;  // bytes from a head's column block in row 0 to its end in row S-1
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(base + d), (short)0, nrec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(base + 2 * d), (short)0, nrec, 0x00020000);
+
+  // per-lane DMA geometry: instruction i of this wave fills tile rows (wid*NI + i)*RPI + lane/CPR, slot lane%CPR
+  const int lr = lane / CPR, ls = lane % CPR;
+  int vk[NI], vv[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int r = (wid * NI + i) * RPI + lr;
+    const int f = (r >> FSH) & FMSK;
+    vk[i] = (r * ld + ((ls ^ f) * 4)) * 4;
+    vv[i] = (r * ld + ls * 4) * 4;
+  }
+  const int tile_step = BC * ld * 4;  // bytes per key tile
+  auto dma_k = [&](float* Kd, int kt) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)&Kd[(wid * NI + i) * RPI * DK], 16, vk[i] + (t0 + kt) * tile_step, 0, 0, 0);
+  };
+  auto dma_v = [&](float* Vd, int kt) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)&Vd[(wid * NI + i) * RPI * DK], 16, vv[i] + (t0 + kt) * tile_step, 0, 0, 0);
+  };
+
+  // Q^T operand: lane (q, h) keeps Q[q][8g + 4h + e], pre-multiplied by log2(e)/sqrt(d_k) so the scores come out
+  // of the MFMA already scaled into the exp2 domain (one multiply per Q element instead of one per score)
+  f32x4 qreg[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (q < S) qreg[g] = *reinterpret_cast<const f32x4*>(base + (size_t)q * ld + 8 * g + 4 * h) * c_scale;
+    else qreg[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  f32x16 o[NDB];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // K fragment read offsets (floats): row qi (the key this lane feeds as MFMA row), slot (2g + h) ^ f(row)
+  int koff[NG];
+  {
+    const int f = (qi >> FSH) & FMSK;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) koff[g] = qi * DK + (((2 * g + h) ^ f) * 4);
+  }
+
+  // S^T[key][q] = sum_d K[key][d] Q[q][d] for the K tile at kp.  TWO accumulator chains (even / odd contraction steps),
+  // added at the end: with one wave per SIMD a single chain of dependent MFMAs issues ~8 % below the pipe's rate
+  // (tools/lab/mfma_chain.hip: 142 vs 155 TFLOP/s).  The steady-state loop below sums in the same order.
+  auto qk = [&](const float* kp, f32x16& s) {
+    f32x16 s2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f, s2[r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const f32x4 kf = *reinterpret_cast<const f32x4*>(kp + koff[g]);
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qreg[g][e], s, 0, 0, 0);
+        s2 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e + 1], qreg[g][e + 1], s2, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] += s2[r];
+  };
+  // key-padding mask + online softmax of tile kt; s becomes P, returns the O rescale factor
+  auto softmax_tile = [&](int kt, f32x16& s) -> float {
+    if ((t0 + kt) * BC + BC > len) {  // wave-uniform: only the tile that straddles lens[b] needs the per-key compare
+      const int kbase = (t0 + kt) * BC + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kbase + (r & 3) + 8 * (r >> 2);
+        s[r] = key < len ? s[r] : -INFINITY;
+      }
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    // Lazy reference point: softmax is exact for ANY reference m as long as exp2(s - m) cannot overflow, so the
+    // running reference only moves when a score exceeds it by more than 2^RESCALE_LOG2 (P stays <= 2^10, far inside
+    // fp32 range and at unchanged relative precision).  After the first tile this almost never fires, which
+    // removes the 64-register O^T rescale (and its accumulator-file round trip) from the steady state.
+    constexpr float RESCALE_LOG2 = 10.f;
+    const bool need = mt > m_run + RESCALE_LOG2;  // (-inf + 10 = -inf: the first finite tile always fires)
+    const float m_new = need ? mt : m_run;
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = need ? __builtin_amdgcn_exp2f(m_run - m_use) : 1.0f;
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
+      psum += s[r];
+    }
+    // keep the exponentials in THIS scheduling region (the one that holds the QK^T MFMAs): without the pin the
+    // optimiser sinks them below pv()'s branch, next to their only consumers
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(s[r]));
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    return alpha;
+  };
+  // O^T[d][q] = alpha * O^T[d][q] + sum_key V[key][d] P[q][key]   (MFMA step r <-> key(r,h), B operand = p[r])
+  auto pv = [&](const float* vtile, const f32x16& pr, float alpha) {
+    const float* vp = vtile + (4 * h) * DK + qi;
+    if (__any(alpha != 1.0f)) {  // wave-uniform; rare after the first tile (lazy reference point)
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = vp[((r & 3) + 8 * (r >> 2)) * DK + 32 * db];
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, pr[r], o[db], 0, 0, 0);
+      }
+    }
+  };
+
+  if (nkt > 0) {
+    dma_k(Ks0, 0);
+    dma_v(Vs0, 0);
+    if (nkt > 1) dma_k(Ks1, 1);
+  }
+  __syncthreads();
+
+  f32x16 s_a, s_b;  // score tiles of even / odd key tiles (static roles in the 2x unrolled loop: no register copies)
+  if (nkt > 0) qk(Ks0, s_a);
+  __syncthreads();  // every wave has read K(0) before its buffer is refilled
+  if (nkt > 2) dma_k(Ks0, 2);
+
+  // ---- steady state: one key tile per call, hand-scheduled -------------------------------------------------------
+  // The wave is alone on its SIMD, so program order IS issue order and nothing else covers a stall.  Left to the
+  // scheduler the loop was: 64 score MFMAs with each K fragment read right before its use, THEN the softmax, THEN the
+  // 64 P V MFMAs with a third of the V reads waited for on the spot — matrix pipe 75 % busy (profiles/r02_pmc.md).
+  // Here the order is written out and pinned with sched_barrier(0) between slices:
+  //   phase 1, NG slices: [read K fragment g+1] [4 MFMAs of S(kt+1)^T with fragment g] [a slice of softmax(kt)]
+  //   ONE barrier (K(kt+1) and V(kt-1) are dead, K(kt+2) has landed) -> refill them with K(kt+3) / V(kt+1)
+  //   phase 2, 16 slices: [read V row r+2] [NDB MFMAs of O^T += V(kt)^T P(kt)^T for key r]; the last slices also read
+  //   the first K fragment of the next call, so phase 1 starts without a wait.
+  // Softmax in units (u): 0-3 lane-local max over 4 scores; 4 cross-half shuffle issued; 5 shuffle consumed, lazy
+  // reference point, alpha; 6-21 one exp2 each; 22-25 (after the barrier, under the first V reads) the row sum.
+  constexpr int U_PH1 = 22;
+  float sm_mt = 0.f, sm_mx = 0.f, sm_muse = 0.f, sm_alpha = 1.f, sm_mnew = 0.f, sm_psum = 0.f;
+  auto sm_unit = [&](int u, f32x16& s) {
+    if (u < 4) {
+      const float a = fmaxf(fmaxf(s[4 * u], s[4 * u + 1]), fmaxf(s[4 * u + 2], s[4 * u + 3]));
+      sm_mt = u == 0 ? a : fmaxf(sm_mt, a);
+    } else if (u == 4) {
+      sm_mx = __shfl_xor(sm_mt, 32);
+    } else if (u == 5) {
+      constexpr float RESCALE_LOG2 = 10.f;  // see softmax_tile
+      const float mt = fmaxf(sm_mt, sm_mx);
+      const bool need = mt > m_run + RESCALE_LOG2;
+      sm_mnew = need ? mt : m_run;
+      sm_muse = (sm_mnew == -INFINITY) ? 0.f : sm_mnew;
+      sm_alpha = need ? __builtin_amdgcn_exp2f(m_run - sm_muse) : 1.0f;
+    } else if (u < 22) {
+      const int r = u - 6;
+      s[r] = __builtin_amdgcn_exp2f(s[r] - sm_muse);
+      asm volatile("" : "+v"(s[r]));  // stays in this slice (the optimiser would sink it next to its consumer MFMA)
+    } else {
+      const int j = u - 22;
+      if (j == 0) sm_psum = 0.f;
+#pragma unroll
+      for (int r = 4 * j; r < 4 * j + 4; ++r) sm_psum += s[r];  // same order as softmax_tile
+      if (j == 3) {
+        l_run = l_run * sm_alpha + sm_psum;
+        m_run = sm_mnew;
+      }
+    }
+  };
+  f32x4 kpre = {0.f, 0.f, 0.f, 0.f};  // fragment 0 of the K tile the next call sweeps
+  if (nkt > 1) kpre = *reinterpret_cast<const f32x4*>(Ks1 + koff[0]);
+
+  auto tile = [&](int kt, float* Kread, const float* Kpre, const float* Vcur, float* Vother, f32x16& s_cur, f32x16& s_next) {
+    // phase 1: S(kt+1)^T = K(kt+1) Q^T on the matrix pipe, softmax(kt) in its shadow.  Never the tile that straddles
+    // lens[b] (only the LAST key tile can, and that one is handled after the loop): no mask, no branch.
+    f32x4 kf = kpre;
+    f32x16 s_odd;  // second accumulator chain of the score tile (see qk); folded into s_next one row per phase-2 slice
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      f32x4 kn = kf;
+#if !defined(NS_LAB_ATT_NOKREAD)
+      if (g + 1 < NG) kn = *reinterpret_cast<const f32x4*>(Kread + koff[g + 1]);
+#endif
+      if (g == 0) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        s_next = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[0], qreg[0][0], z, 0, 0, 0);
+        s_odd = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[1], qreg[0][1], z, 0, 0, 0);
+        s_next = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[2], qreg[0][2], s_next, 0, 0, 0);
+        s_odd = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[3], qreg[0][3], s_odd, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          s_next = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qreg[g][e], s_next, 0, 0, 0);
+          s_odd = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e + 1], qreg[g][e + 1], s_odd, 0, 0, 0);
+        }
+      }
+#if !defined(NS_LAB_ATT_NOSM)
+#pragma unroll
+      for (int u = (g * U_PH1) / NG; u < ((g + 1) * U_PH1) / NG; ++u) sm_unit(u, s_cur);
+#endif
+      kf = kn;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#if !defined(NS_LAB_ATT_NOBAR)
+    __syncthreads();  // the DMA issued one call ago has landed (K(kt+2), V(kt)); K(kt+1) and V(kt-1) are dead
+#endif
+#if !defined(NS_LAB_ATT_NODMA)
+    if (kt + 3 < nkt) dma_k(Kread, kt + 3);
+    dma_v(Vother, kt + 1);
+#endif
+    // phase 2: O^T = alpha O^T + V(kt)^T P(kt)^T; MFMA step r <-> key(r,h) (see pv)
+    const float* vp = Vcur + (4 * h) * DK + qi;
+    float vr[3][NDB];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) vr[r][db] = vp[((r & 3) + 8 * (r >> 2)) * DK + 32 * db];
+#pragma unroll
+    for (int u = U_PH1; u < U_PH1 + 4; ++u) sm_unit(u, s_cur);
+    __builtin_amdgcn_sched_barrier(0);
+    if (__any(sm_alpha != 1.0f)) {  // wave-uniform; rare after the first tile (lazy reference point)
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= sm_alpha;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r + 2 < 16) {
+#pragma unroll
+#if defined(NS_LAB_ATT_NOVREAD)
+        for (int db = 0; db < NDB; ++db) vr[(r + 2) % 3][db] = qreg[r][db & 3];
+#else
+        for (int db = 0; db < NDB; ++db) vr[(r + 2) % 3][db] = vp[(((r + 2) & 3) + 8 * ((r + 2) >> 2)) * DK + 32 * db];
+#endif
+      }
+      if (r == 14) kpre = *reinterpret_cast<const f32x4*>(Kpre + koff[0]);
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[r % 3][db], s_cur[r], o[db], 0, 0, 0);
+      s_next[r] += s_odd[r];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  for (int kt = 0; kt + 1 < nkt; kt += 2) {
+    tile(kt, Ks1, Ks0, Vs0, Vs1, s_a, s_b);
+    if (kt + 2 < nkt) tile(kt + 1, Ks0, Ks1, Vs1, Vs0, s_b, s_a);
+  }
+  if (nkt > 1) __syncthreads();  // V(nkt-1), issued in the last call, has landed
+  if (nkt > 0) {
+    if ((nkt - 1) & 1) {
+      const float alpha = softmax_tile(nkt - 1, s_b);
+      pv(Vs1, s_b, alpha);
+    } else {
+      const float alpha = softmax_tile(nkt - 1, s_a);
+      pv(Vs0, s_a, alpha);
+    }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  if (opart) {  // split-key mode: un-normalised partial for the merge kernel
+    if (q < S) {
+      const size_t row = (size_t)sp * gridDim.z * S + (size_t)b * S + q;
+      float* dst = opart + row * d + hd * DK + 4 * h;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          *reinterpret_cast<f32x4*>(dst + 32 * db + 8 * u) = f32x4{o[db][4 * u], o[db][4 * u + 1], o[db][4 * u + 2], o[db][4 * u + 3]};
+      if (h == 0) {
+        mlpart[(row * gridDim.y + hd) * 2] = m_run;
+        mlpart[(row * gridDim.y + hd) * 2 + 1] = l_tot;
+      }
+    }
+    return;
+  }
+  const float inv = 1.0f / l_tot;   // lens[b]==0 -> 0 * inf = NaN, as the reference
+  if (q < S) {
+    float* dst = out + ((size_t)b * S + q) * d + hd * DK + 4 * h;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f32x4 v = {o[db][4 * u] * inv, o[db][4 * u + 1] * inv, o[db][4 * u + 2] * inv, o[db][4 * u + 3] * inv};
+        *reinterpret_cast<f32x4*>(dst + 32 * db + 8 * u) = v;
+      }
+  }
+#endif
+}
+
+// out[row, c] = sum_sp O_sp[row, c] 2^(m_sp - m) / sum_sp l_sp 2^(m_sp - m), m = max_sp m_sp (per row and head)
+__global__ __launch_bounds__(256) void k_attention_merge(const float* __restrict__ opart, const float* __restrict__ mlpart, int M,
+                                                          int d, int H, int dk, int nsplit, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  for (int c = lane * 4; c < d; c += 256) {
+    const int hd = c / dk;
+    float mx = -INFINITY;
+    for (int sp = 0; sp < nsplit; ++sp) mx = fmaxf(mx, mlpart[(((size_t)sp * M + m) * H + hd) * 2]);
+    const float m_use = (mx == -INFINITY) ? 0.f : mx;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float l = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+      const size_t row = (size_t)sp * M + m;
+      const float w = __builtin_amdgcn_exp2f(mlpart[(row * H + hd) * 2] - m_use);
+      l += mlpart[(row * H + hd) * 2 + 1] * w;
+      acc += *reinterpret_cast<const f32x4*>(opart + row * d + c) * w;
+    }
+    const float inv = 1.0f / l;  // no valid key at all -> 0 * inf = NaN, as the reference
+    *reinterpret_cast<f32x4*>(out + (size_t)m * d + c) = acc * inv;
+  }
+}
+
+hipError_t launch_attention(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, float* scratch,
+                            size_t scratch_floats, hipStream_t st) {
+  if (B <= 0 || S <= 0) return hipSuccess;
+  const int d = H * dk;
+  if ((long long)S * 3 * d * 4 >= (1ll << 31)) return hipErrorInvalidValue;  // 31-bit descriptor offsets per utterance
+  const float c = 1.4426950408889634f / sqrtf((float)dk);
+  const int qtiles = (S + 127) / 128;
+  // Few workgroups (single-utterance latency): a workgroup's time is its serial sweep over the key tiles, 128 fp32
+  // MFMAs per tile and wave, so split the sweep over up to ATT_SPLIT_MAX workgroups per query tile until the launch
+  // has ~256 of them, then merge the partials.  Needs nsplit * (M*d + 2*M*H) floats of scratch.
+  int nsplit = 1;
+  const long blocks = (long)qtiles * H * B;
+  const size_t M = (size_t)B * S;
+  if (scratch && blocks < ATT_SPLIT_MAX_BLOCKS) {
+    nsplit = (int)(256 / blocks);
+    if (nsplit > ATT_SPLIT_MAX) nsplit = ATT_SPLIT_MAX;
+    if (nsplit > (S + 31) / 32) nsplit = (S + 31) / 32;  // at least one 32-key tile each
+    while (nsplit > 1 && (size_t)nsplit * (M * d + 2 * M * H) > scratch_floats) --nsplit;
+    if (nsplit < 1) nsplit = 1;
+  }
+  float* opart = nsplit > 1 ? scratch : nullptr;
+  float* mlpart = nsplit > 1 ? scratch + (size_t)nsplit * M * d : nullptr;
+  dim3 grid(qtiles * nsplit, H, B), block(256);
+  if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart);
+  else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart);
+  else if (dk == 32) hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart);
+  else return hipErrorInvalidValue;
+  if (nsplit > 1)
+    hipLaunchKernelGGL(k_attention_merge, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, opart, mlpart, (int)M, d, H, dk, nsplit, out);
+  return hipGetLastError();
+}
+
+}  // namespace ns
