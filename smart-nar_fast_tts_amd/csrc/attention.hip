@@ -316,6 +316,8 @@ hipError_t launch_attention(const float* qkv, const long long* lens, int B, int 
     if (nsplit > (S + 31) / 32) nsplit = (S + 31) / 32;  // at least one 32-key tile each
     while (nsplit > 1 && (size_t)nsplit * (M * d + 2 * M * H) > scratch_floats) --nsplit;
     if (nsplit < 1) nsplit = 1;
+    const int tiles = (S + 31) / 32, tps = (tiles + nsplit - 1) / nsplit;
+    nsplit = (tiles + tps - 1) / tps;  // no empty ranges: 25 tiles over 16 ranges are 13 ranges of two
   }
   float* opart = nsplit > 1 ? scratch : nullptr;
   float* mlpart = nsplit > 1 ? scratch + (size_t)nsplit * M * d : nullptr;
