@@ -52,10 +52,10 @@ int main() {
     for (int r = 0; r < 3; ++r) { CK(hipEventRecord(a, 0)); for (int i = 0; i < 20; ++i) CK(launch_conv_gemm(p, 0)); CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms / 20 < best ? ms / 20 : best; }
     printf("%s %.2f GFLOP\n   shipped choice %37.1f us %6.1f TF/s\n", s.name, gf, best * 1e3, gf / best);
     run<64, 256, 32, 1, 2, 4>(p, gf, ny);
+    run<128, 256, 16, 1, 2, 4>(p, gf, ny);
+    run<128, 128, 16, 1, 2, 2>(p, gf, ny);
+    run<64, 256, 16, 1, 2, 4>(p, gf, ny);
     run<128, 256, 32, 1, 2, 4>(p, gf, ny);
-    run<128, 128, 32, 1, 2, 2>(p, gf, ny);
-    run<128, 256, 32, 1, 4, 4>(p, gf, ny);
-    run<64, 256, 32, 1, 1, 4>(p, gf, ny);
     run<64, 256, 32, 1, 2, 4>(p, gf, ny);
     CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(db)); CK(hipFree(dy));
   }
