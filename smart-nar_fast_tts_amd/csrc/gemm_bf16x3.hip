@@ -95,13 +95,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gemm_b3(ConvGemm p, int
       __builtin_amdgcn_make_buffer_rsrc((void*)(p.Wb3 + (size_t)n0 * Kt), (short)0, 0x7FFFFFFF, 0x00020000);
 
   // A: 8 lanes per 128-B row, source-side swizzle f(r) = (r>>1)&7 on the 16-B slot (gemm_conv.hip, BK = 32)
-  int a_row[IA], a_t[IA], a_col[IA];
+  // byte offset without the tap shift + the range of taps that stay inside the utterance (see gemm_conv.hip)
+  int a_base[IA];
+  unsigned a_jlo[IA], a_jn[IA];
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
     const int r = (wid * IA + i) * 8 + (lane >> 3), m = m0 + r;
-    a_row[i] = r;
-    a_t[i] = (m < p.M) ? (m % p.S) : -1;
-    a_col[i] = ((lane & 7) ^ ((r >> 1) & 7)) * 4;
+    const int t = (m < p.M) ? (m % p.S) : -1;
+    a_base[i] = (r * p.ldx + ((lane & 7) ^ ((r >> 1) & 7)) * 4) * 4;
+    const int jlo = max(0, p.pad - t), jhi = min(p.KW, p.S + p.pad - t);
+    a_jlo[i] = (unsigned)jlo;
+    a_jn[i] = (t >= 0 && jhi > jlo) ? (unsigned)(jhi - jlo) : 0u;
   }
   // B planes: 4 lanes per 64-B row (32 bf16), swizzle f(r) = (r>>2)&3 on the 16-B slot (the 64-B-row rule of gemm_conv.hip)
   int vb[IB];
@@ -112,12 +116,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gemm_b3(ConvGemm p, int
   }
   auto dma_chunk = [&](float* As, unsigned short* Bs, int ch) {
     const int cc = ch / p.KW, j = ch - cc * p.KW;  // channel-block major, tap minor (L2 reuse of the activation lines)
-    const int soA = cc * BK * 4;
+    const int soA = (cc * BK + j * p.ldx) * 4;
     const int k0 = j * p.Cin + cc * BK;
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-      const int ts = a_t[i] + j - p.pad;
-      const int va = (a_t[i] >= 0 && ts >= 0 && ts < p.S) ? ((a_row[i] + j) * p.ldx + a_col[i]) * 4 : OOR3;
+      const int va = ((unsigned)j - a_jlo[i] < a_jn[i]) ? a_base[i] : OOR3;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr3_t)&As[(wid * IA + i) * 8 * BK], 16, va, soA, 0, 0);
     }
 #pragma unroll

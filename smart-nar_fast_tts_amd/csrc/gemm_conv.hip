@@ -113,14 +113,21 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
   // entry taken by round i of this wave: a contiguous run per wave when the list divides evenly, strided otherwise
   auto ea = [&](int i) { return A_EVEN ? wid * IA + i : i * NW + wid; };
   auto eb = [&](int i) { return B_EVEN ? wid * IB + i : i * NW + wid; };
-  int a_row[IA], a_t[IA], a_col[IA];  // tile row, position inside the utterance (-1: row >= M), swizzled column
+  // Per A entry of this lane: byte offset of (tile row, swizzled column) WITHOUT the tap shift, and the range of taps
+  // [a_jlo, a_jlo + a_jn) for which the shifted row is inside its utterance (empty for rows >= M).  The tap's row shift
+  // j * ldx goes into the DMA's scalar offset, so a chunk costs three VALU ops per entry (sub, compare, select) instead of
+  // the multiply-add chain — VALU issue next to the MFMAs is not free (tools/lab/mfma_mix.hip).
+  int a_base[IA];
+  unsigned a_jlo[IA], a_jn[IA];
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
     const int r = ea(i) * RPI + lr;
     const int m = m0 + r;
-    a_row[i] = r;
-    a_t[i] = (m < p.M) ? (m % p.S) : -1;
-    a_col[i] = (ls ^ ((r >> FSH) & FMSK)) * 4;
+    const int t = (m < p.M) ? (m % p.S) : -1;
+    a_base[i] = (r * p.ldx + (ls ^ ((r >> FSH) & FMSK)) * 4) * 4;
+    const int jlo = max(0, p.pad - t), jhi = min(p.KW, p.S + p.pad - t);
+    a_jlo[i] = (unsigned)jlo;
+    a_jn[i] = (t >= 0 && jhi > jlo) ? (unsigned)(jhi - jlo) : 0u;
   }
   int vb[IB];
 #pragma unroll
@@ -134,11 +141,10 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
   // uses of a line — a reuse distance of 2-5 MB against a 4 MB L2: 2-4x the fabric traffic, profiles/r01_pmc.md.)
   auto dma_chunk = [&](float* As, float* Bs, int ch) {
     const int cc = ch / p.KW, j = ch - cc * p.KW;
-    const int soA = cc * BK * 4, soB = (j * p.Cin + cc * BK) * 4;
+    const int soA = (cc * BK + j * p.ldx) * 4, soB = (j * p.Cin + cc * BK) * 4;
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-      const int ts = a_t[i] + j - p.pad;
-      const int va = (a_t[i] >= 0 && ts >= 0 && ts < p.S) ? ((a_row[i] + j) * p.ldx + a_col[i]) * 4 : OOR;
+      const int va = ((unsigned)j - a_jlo[i] < a_jn[i]) ? a_base[i] : OOR;
       if (A_EVEN || ea(i) < TOTA)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)&As[ea(i) * RPI * BK], 16, va, soA, 0, 0);
     }
