@@ -203,6 +203,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gemm_b3(ConvGemm p, int
     // full-row tile (BN == N): the same row epilogue as gemm_conv.hip's (rowln.h) — LayerNorm (+ mask) of act(acc + bias) +
     // residual, one row per wave64; rows [0,32) of the tile are parked in Bs0, [32,64) in Bs1
     auto trow = [&](int ml) -> float* { return reinterpret_cast<float*>(ml < 32 ? Bs0 : Bs1) + (ml & 31) * BN; };
+    // residual rows of this wave, all loads in flight before the tile is parked (see gemm_conv.hip)
+    constexpr int NV = BN / 256, RPW = BM / NW;
+    f32x4 rv[RPW][NV];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int m = m0 + wid * RPW + rr;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        rv[rr][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.resid && m < p.M) rv[rr][i] = *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + lane * 4 + i * 256);
+      }
+    }
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
       const int nl = wn0 + ni * 32 + ecol;
@@ -217,27 +229,27 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gemm_b3(ConvGemm p, int
       }
     }
     __syncthreads();
-    constexpr int NV = BN / 256, RPW = BM / NW;
-#pragma unroll 1
+#pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int ml = wid * RPW + rr, m = m0 + ml;
-      if (m >= p.M) break;
-      const int b = m / p.S, t = m - b * p.S;
-      const bool masked = p.e.lens && (long long)t >= p.e.lens[b];
-      if (masked) {
+      if (m < p.M) {
+        const int b = m / p.S, t = m - b * p.S;
+        const bool masked = p.e.lens && (long long)t >= p.e.lens[b];
+        if (masked) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + lane * 4 + i * 256) = f32x4{0.f, 0.f, 0.f, 0.f};
-        continue;
-      }
-      f32x4 v[NV];
+          for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + lane * 4 + i * 256) = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+          f32x4 v[NV];
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        v[i] = *reinterpret_cast<const f32x4*>(trow(ml) + lane * 4 + i * 256);
-        if (p.resid) v[i] += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + lane * 4 + i * 256);
+          for (int i = 0; i < NV; ++i) {
+            v[i] = *reinterpret_cast<const f32x4*>(trow(ml) + lane * 4 + i * 256);
+            if (p.resid) v[i] += rv[rr][i];
+          }
+          float mean, rstd;
+          ln_moments<NV>(v, BN, lane, mean, rstd);
+          ln_store<NV>(v, BN, lane, mean, rstd, p.e.ln_g, p.e.ln_b, p.Y + (size_t)m * p.ldy);
+        }
       }
-      float mean, rstd;
-      ln_moments<NV>(v, BN, lane, mean, rstd);
-      ln_store<NV>(v, BN, lane, mean, rstd, p.e.ln_g, p.e.ln_b, p.Y + (size_t)m * p.ldy);
     }
   } else {
 #pragma unroll

@@ -246,6 +246,19 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
     // then every wave takes BM / waves whole rows — one row per wave64, float4 lanes — and runs the row kernel's own
     // code on them (rowln.h): residual add, LayerNorm, mask / predictor tail, coalesced 1-KB row stores.
     auto trow = [&](int ml) -> float* { return (ml < BK ? Bs0 : Bs1) + (ml % BK) * BN; };  // rows [0,BK) in Bs0, [BK,2BK) in Bs1
+    // the residual rows this wave will need: all loads issued now, so that their latency runs under the parking stores
+    // and the barrier instead of once per row inside the row loop
+    constexpr int NV = BN / 256, RPW = BM / NW;
+    f32x4 rv[RPW][NV];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int m = m0 + wid * RPW + rr;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        rv[rr][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.resid && m < p.M) rv[rr][i] = *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + lane * 4 + i * 256);
+      }
+    }
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
       const int nl = wn0 + ni * 32 + ecol;
@@ -263,28 +276,28 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
       }
     }
     __syncthreads();
-    constexpr int NV = BN / 256, RPW = BM / NW;
-#pragma unroll 1
+#pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int ml = wid * RPW + rr, m = m0 + ml;
-      if (m >= p.M) break;
-      const int b = m / p.S, t = m - b * p.S;
-      const bool masked = p.e.lens && (long long)t >= p.e.lens[b];
-      if (p.epi == EPI_LN && masked) {  // masked_fill(mask, 0): a padded row is written, never computed
+      if (m < p.M) {
+        const int b = m / p.S, t = m - b * p.S;
+        const bool masked = p.e.lens && (long long)t >= p.e.lens[b];
+        if (p.epi == EPI_LN && masked) {  // masked_fill(mask, 0): a padded row is written, never computed
 #pragma unroll
-        for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + lane * 4 + i * 256) = f32x4{0.f, 0.f, 0.f, 0.f};
-        continue;
-      }
-      f32x4 v[NV];
+          for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + lane * 4 + i * 256) = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+          f32x4 v[NV];
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        v[i] = *reinterpret_cast<const f32x4*>(trow(ml) + lane * 4 + i * 256);
-        if (p.resid) v[i] += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + lane * 4 + i * 256);
+          for (int i = 0; i < NV; ++i) {
+            v[i] = *reinterpret_cast<const f32x4*>(trow(ml) + lane * 4 + i * 256);
+            if (p.resid) v[i] += rv[rr][i];
+          }
+          float mean, rstd;
+          ln_moments<NV>(v, BN, lane, mean, rstd);
+          if (p.epi == EPI_LN) ln_store<NV>(v, BN, lane, mean, rstd, p.e.ln_g, p.e.ln_b, p.Y + (size_t)m * p.ldy);
+          else predictor_row_tail<NV>(v, BN, lane, mean, rstd, p.e, m, t, masked);
+        }
       }
-      float mean, rstd;
-      ln_moments<NV>(v, BN, lane, mean, rstd);
-      if (p.epi == EPI_LN) ln_store<NV>(v, BN, lane, mean, rstd, p.e.ln_g, p.e.ln_b, p.Y + (size_t)m * p.ldy);
-      else predictor_row_tail<NV>(v, BN, lane, mean, rstd, p.e, m, t, masked);
     }
   } else {
 #pragma unroll
