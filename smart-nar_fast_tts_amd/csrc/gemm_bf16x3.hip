@@ -257,6 +257,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gemm_b3(ConvGemm p, int
       const int n = n0 + wn0 + ni * 32 + ecol;
       if (n >= p.N) continue;
       const float bv = p.bias ? p.bias[n] : 0.f;
+      float rs[16];  // residual values first, all loads in flight together (see gemm_conv.hip)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + erow;
+        rs[r] = (p.resid && m < p.M) ? p.resid[(size_t)m * p.ldr + n] : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + erow;
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gemm_b3(ConvGemm p, int
         float v = acc[ni][r] + bv;
         if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
         else if (p.act == ACT_TANH) v = tanhf(v);
-        if (p.resid) v += p.resid[(size_t)m * p.ldr + n];
+        if (p.resid) v += rs[r];
         p.Y[(size_t)m * p.ldy + n] = v;
       }
     }

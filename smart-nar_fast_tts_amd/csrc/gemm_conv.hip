@@ -307,6 +307,14 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
       const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
+        // the tile's 16 residual values first, all loads in flight together: interleaved with the stores (Y may alias
+        // resid for all the compiler knows) every element paid a full load + store round trip, 16 in a row
+        float rs[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + erow;
+          rs[r] = (p.resid && m < p.M) ? p.resid[(size_t)m * p.ldr + n] : 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + erow;
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
           float v = acc[mi][ni][r] + bv;
           if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
           else if (p.act == ACT_TANH) v = tanhf(v);
-          if (p.resid) v += p.resid[(size_t)m * p.ldr + n];
+          if (p.resid) v += rs[r];
           p.Y[(size_t)m * p.ldy + n] = v;
         }
       }
