@@ -372,6 +372,11 @@ hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) {
     if (rows64 >= 512) return launch_t<64, 96, 32, 1, 2, 3>(p, st);
     if (rows32 >= 400) return launch_t<32, 96, 32, 4, 1, 3>(p, st);
   }
+  // short contraction, wide output (the QKV projection: K = d, N = 3d): 8-16 K steps per tile, so prologue and epilogue weigh
+  // as much as the loop and three 64x128 workgroups per CU interleave them better than two 64x256 ones.  Measured in the
+  // FORWARD (alternating same-box runs; the lab loop had it the other way round at config 5): config 2 5.476 -> 5.456 ms,
+  // config 4 57.50 -> 57.33 ms, config 5 unchanged.
+  if (bk32 && p.N >= 512 && p.KW * p.Cin <= 512 && wgs(rows64, 128) > 256) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
   if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400) return launch_t<64, 256, 32, 1, 2, 4>(p, st);
   if (bk32 && p.N >= 128 && wgs(rows64, 128) > 256) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
   // Fewer output tiles than that (encoder-side GEMMs, single-utterance latency): a workgroup's time is set by how fast
