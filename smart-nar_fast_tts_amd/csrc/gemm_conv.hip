@@ -377,6 +377,11 @@ hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) {
   // FORWARD (alternating same-box runs; the lab loop had it the other way round at config 5): config 2 5.476 -> 5.456 ms,
   // config 4 57.50 -> 57.33 ms, config 5 unchanged.
   if (bk32 && p.N >= 512 && p.KW * p.Cin <= 512 && wgs(rows64, 128) > 256) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
+  // ... unless the whole launch is at most two rounds of ONE 16-wave workgroup per CU (config 2: 508 tiles for the decoder's
+  // k=9 GEMM, 254 for a PostNet layer): then the 128x256 tile — same 32x64 per wave, half the passes over the weights —
+  // is ahead in the forward (alternating same-box runs: k=9 GEMM 552.7 -> 547.6 us, PostNet layer 311.9 -> 306.8 us, step
+  // 5.463 -> 5.440 ms), while at config 4 (8.4 rounds) it loses 4 % and at config 5 (3.8 rounds) it ties.
+  if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400 && wgs((p.M + 127) / 128, 256) <= 512) return launch_t<128, 256, 32, 1, 4, 4>(p, st);
   if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400) return launch_t<64, 256, 32, 1, 2, 4>(p, st);
   if (bk32 && p.N >= 128 && wgs(rows64, 128) > 256) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
   // Fewer output tiles than that (encoder-side GEMMs, single-utterance latency): a workgroup's time is set by how fast

@@ -45,7 +45,10 @@ under = json.load(open(f"{G}/{ROUND}_bench_under_trace.json"))
 # HIP-event average of the same launches in the same process.
 import sqlite3
 con = sqlite3.connect(f"{G}/{ROUND}_trace/t_results.db")
-rows = con.execute("select start, end, grid_x / workgroup_x as wgs from kernels where name like '%k_conv_gemm<64, 256, 32, 1, 2, 4%' order by start").fetchall()
+top = con.execute("select name, grid_x / workgroup_x as wgs, sum(end - start) as tot from kernels where name like '%k_conv_gemm<%' "
+                  "group by name, wgs order by tot desc limit 1").fetchone()
+dom_name = re.sub(r"\(.*", "", top[0]).replace("void ", "").replace("ns::", "") if top else ""
+rows = con.execute("select start, end, grid_x / workgroup_x as wgs from kernels where name = ? order by start", (top[0],)).fetchall() if top else []
 if rows:
     big = max(r[2] for r in rows)
     durs = [(r[1] - r[0]) / 1e3 for r in rows if r[2] == big]
@@ -56,7 +59,7 @@ if rows:
                                         "hip_event_avg_us_in_bench": round(under["roofline"]["avg_launch_ms"] * 1e3, 1)}
     with open(f"profiles/{ROUND}_kernel_stats.md", "a") as fh:
         fh.write(f"\nDominant kernel, timed region only (last {len(timed)} of {len(durs)} launches of the {int(big)}-workgroup "
-                 f"`k_conv_gemm<64, 256, 32, 1, 2, 4>`): rocprofv3 avg {sum(timed) / len(timed):.1f} us; bench.py's HIP events "
+                 f"`{dom_name}`): rocprofv3 avg {sum(timed) / len(timed):.1f} us; bench.py's HIP events "
                  f"around the same launches in the same process: {under['roofline']['avg_launch_ms'] * 1e3:.1f} us.\n")
 
 
