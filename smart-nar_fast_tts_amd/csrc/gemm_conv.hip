@@ -346,7 +346,7 @@ hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if (p.Cin % 16 != 0 || (p.ldx & 3) != 0) return hipErrorInvalidValue;
   // descriptor offsets are 31-bit: a tile's rows (BM + KW) * ldx and BN * K floats must stay below 2^29 floats
-  if ((long long)(128 + p.KW) * p.ldx >= (1ll << 29) || (long long)512 * p.KW * p.Cin >= (1ll << 29)) return hipErrorInvalidValue;
+  if ((long long)(256 + p.KW) * p.ldx >= (1ll << 29) || (long long)512 * p.KW * p.Cin >= (1ll << 29)) return hipErrorInvalidValue;
   if (p.epi != EPI_NONE) {
     // full-row tile: 32 rows x N columns, N / 32 waves side by side with one 32x32 MFMA tile each
     if (!conv_gemm_row_epilogue_ok(p.M, p.N, p.Cin) || (p.ldy & 3) || (p.resid && (p.ldr & 3))) return hipErrorInvalidValue;
@@ -377,11 +377,18 @@ hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) {
   // FORWARD (alternating same-box runs; the lab loop had it the other way round at config 5): config 2 5.476 -> 5.456 ms,
   // config 4 57.50 -> 57.33 ms, config 5 unchanged.
   if (bk32 && p.N >= 512 && p.KW * p.Cin <= 512 && wgs(rows64, 128) > 256) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
-  // ... unless the whole launch is at most two rounds of ONE 16-wave workgroup per CU (config 2: 508 tiles for the decoder's
-  // k=9 GEMM, 254 for a PostNet layer): then the 128x256 tile — same 32x64 per wave, half the passes over the weights —
-  // is ahead in the forward (alternating same-box runs: k=9 GEMM 552.7 -> 547.6 us, PostNet layer 311.9 -> 306.8 us, step
-  // 5.463 -> 5.440 ms), while at config 4 (8.4 rounds) it loses 4 % and at config 5 (3.8 rounds) it ties.
-  if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400 && wgs((p.M + 127) / 128, 256) <= 512) return launch_t<128, 256, 32, 1, 4, 4>(p, st);
+  // ... unless a taller 16-wave tile, one workgroup per CU, fills its rounds: fewer passes over the weights, and with one
+  // or two rounds there is nothing a second co-resident workgroup could hide.  Settled by alternating whole-forward runs on
+  // one box (tools/ab_forward.sh), per launch: 256x256 — decoder k=9 GEMM 547.7 -> 539.7 us at config 2 (254 tiles, one round),
+  // 1096 -> 1075 us at config 5 (492 tiles, two rounds), PostNet layer 604 -> 598 us at config 5; 128x256 — PostNet layer
+  // 311.9 -> 306.8 us at config 2 (254 tiles).  Rounds that do not fill lose badly (config 4: 540 tiles of 256x256 = 2.1
+  // rounds: PostNet layer +30 %; 2156 tiles of 128x256 = 8.4 rounds: k=9 GEMM +6 %), hence the fill tests.
+  if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400) {
+    auto fill = [](long n) { return (double)n / (double)(((n + 255) / 256) * 256); };  // of the last round, one workgroup per CU
+    const long c256 = wgs((p.M + 255) / 256, 256), c128 = wgs((p.M + 127) / 128, 256);
+    if (c256 >= 200 && fill(c256) >= 0.95) return launch_t<256, 256, 32, 1, 8, 2>(p, st);
+    if (c128 <= 512 && fill(c128) >= 0.95) return launch_t<128, 256, 32, 1, 4, 4>(p, st);
+  }
   if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400) return launch_t<64, 256, 32, 1, 2, 4>(p, st);
   if (bk32 && p.N >= 128 && wgs(rows64, 128) > 256) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
   // Fewer output tiles than that (encoder-side GEMMs, single-utterance latency): a workgroup's time is set by how fast
