@@ -190,7 +190,11 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   };
   // O^T[d][q] = alpha * O^T[d][q] + sum_key V[key][d] P[q][key]   (MFMA step r <-> key(r,h), B operand = p[r])
   auto pv = [&](const float* vtile, const f32x16& pr, float alpha) {
-    const float* vp = vtile + (4 * h) * DK + qi;
+    // O^T block db, row i (= this lane's qi as the A-operand row) is output column d = NDB*i + db — NOT 32*db + i: the NDB
+    // values a lane feeds for one key are then adjacent in the V tile, one ds_read_b128 (b64 for d_k = 64) instead of NDB
+    // ds_read_b32; MFMA rows are just labels, the stores below use the same labelling.  LDS instruction issue is not free
+    // next to the MFMAs (tools/lab/mfma_mix.hip): 32 instead of 48 LDS reads per key tile.
+    const float* vp = vtile + (4 * h) * DK + NDB * qi;
     if (__any(alpha != 1.0f)) {  // wave-uniform; rare after the first tile (lazy reference point)
 #pragma unroll
       for (int db = 0; db < NDB; ++db)
@@ -198,10 +202,12 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
     }
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) {
+    for (int r = 0; r < 16; ++r) {
+      typedef float vrow_t __attribute__((ext_vector_type(NDB)));
+      const vrow_t vv = *reinterpret_cast<const vrow_t*>(vp + ((r & 3) + 8 * (r >> 2)) * DK);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = vp[((r & 3) + 8 * (r >> 2)) * DK + 32 * db];
+      for (int db = 0; db < NDB; ++db) {
+        const float v = vv[db];
         o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, pr[r], o[db], 0, 0, 0);
       }
     }
@@ -246,12 +252,16 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   if (opart) {  // split-key mode: un-normalised partial for the merge kernel
     if (q < S) {
       const size_t row = (size_t)sp * gridDim.z * S + (size_t)b * S + q;
-      float* dst = opart + row * d + hd * DK + 4 * h;
+      float* dst = opart + row * d + hd * DK + NDB * 4 * h;
 #pragma unroll
-      for (int db = 0; db < NDB; ++db)
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          *reinterpret_cast<f32x4*>(dst + 32 * db + 8 * u) = f32x4{o[db][4 * u], o[db][4 * u + 1], o[db][4 * u + 2], o[db][4 * u + 3]};
+        for (int k = 0; k < NDB; ++k) {  // 4*NDB adjacent columns d = NDB*(8u + 4h + j) + db, element e = NDB*j + db
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = o[(4 * k + e) % NDB][4 * u + (4 * k + e) / NDB];
+          *reinterpret_cast<f32x4*>(dst + NDB * 8 * u + 4 * k) = v;
+        }
       if (h == 0) {
         mlpart[(row * gridDim.y + hd) * 2] = m_run;
         mlpart[(row * gridDim.y + hd) * 2 + 1] = l_tot;
@@ -261,13 +271,15 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   }
   const float inv = 1.0f / l_tot;   // lens[b]==0 -> 0 * inf = NaN, as the reference
   if (q < S) {
-    float* dst = out + ((size_t)b * S + q) * d + hd * DK + 4 * h;
+    float* dst = out + ((size_t)b * S + q) * d + hd * DK + NDB * 4 * h;
 #pragma unroll
-    for (int db = 0; db < NDB; ++db)
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        f32x4 v = {o[db][4 * u] * inv, o[db][4 * u + 1] * inv, o[db][4 * u + 2] * inv, o[db][4 * u + 3] * inv};
-        *reinterpret_cast<f32x4*>(dst + 32 * db + 8 * u) = v;
+      for (int k = 0; k < NDB; ++k) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = o[(4 * k + e) % NDB][4 * u + (4 * k + e) / NDB] * inv;
+        *reinterpret_cast<f32x4*>(dst + NDB * 8 * u + 4 * k) = v;
       }
   }
 #endif
