@@ -188,13 +188,19 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     m_run = m_new;
     return alpha;
   };
+  // g: MFMA row i = 8u + 4h' + j  ->  8u + (j / JP) * 2 JP + h' * JP + j % JP, JP = 4 / NDB rows per 16-byte piece (see pv)
+  constexpr int JP = 4 / NDB;
+  auto row_label = [](int i) { return (i & ~7) + ((i & 3) / JP) * (2 * JP) + ((i >> 2) & 1) * JP + (i & 3) % JP; };
   // O^T[d][q] = alpha * O^T[d][q] + sum_key V[key][d] P[q][key]   (MFMA step r <-> key(r,h), B operand = p[r])
   auto pv = [&](const float* vtile, const f32x16& pr, float alpha) {
-    // O^T block db, row i (= this lane's qi as the A-operand row) is output column d = NDB*i + db — NOT 32*db + i: the NDB
+    // O^T block db, row i (= this lane's qi as the A-operand row) is output column d = NDB*g(i) + db — NOT 32*db + i: the NDB
     // values a lane feeds for one key are then adjacent in the V tile, one ds_read_b128 (b64 for d_k = 64) instead of NDB
     // ds_read_b32; MFMA rows are just labels, the stores below use the same labelling.  LDS instruction issue is not free
     // next to the MFMAs (tools/lab/mfma_mix.hip): 32 instead of 48 LDS reads per key tile.
-    const float* vp = vtile + (4 * h) * DK + NDB * qi;
+    // ... with the rows of an 8-row group permuted (g below) so that in the C/D layout the two lane halves of a query hold
+    // ADJACENT 16-byte pieces: a store instruction then writes 32 contiguous bytes per output row, as before the relabelling
+    // (16-byte pieces 64 bytes apart cost 2.5 us per workgroup in the epilogue).
+    const float* vp = vtile + (4 * h) * DK + NDB * row_label(qi);
     if (__any(alpha != 1.0f)) {  // wave-uniform; rare after the first tile (lazy reference point)
 #pragma unroll
       for (int db = 0; db < NDB; ++db)
@@ -252,15 +258,15 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   if (opart) {  // split-key mode: un-normalised partial for the merge kernel
     if (q < S) {
       const size_t row = (size_t)sp * gridDim.z * S + (size_t)b * S + q;
-      float* dst = opart + row * d + hd * DK + NDB * 4 * h;
+      float* dst = opart + row * d + hd * DK + 4 * h;
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int k = 0; k < NDB; ++k) {  // 4*NDB adjacent columns d = NDB*(8u + 4h + j) + db, element e = NDB*j + db
+        for (int pj = 0; pj < NDB; ++pj) {  // piece pj of row group u: rows j = pj*JP + e/NDB, block db = e%NDB
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = o[(4 * k + e) % NDB][4 * u + (4 * k + e) / NDB];
-          *reinterpret_cast<f32x4*>(dst + NDB * 8 * u + 4 * k) = v;
+          for (int e = 0; e < 4; ++e) v[e] = o[e % NDB][4 * u + pj * JP + e / NDB];
+          *reinterpret_cast<f32x4*>(dst + 8 * NDB * u + 8 * pj) = v;
         }
       if (h == 0) {
         mlpart[(row * gridDim.y + hd) * 2] = m_run;
@@ -271,15 +277,15 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   }
   const float inv = 1.0f / l_tot;   // lens[b]==0 -> 0 * inf = NaN, as the reference
   if (q < S) {
-    float* dst = out + ((size_t)b * S + q) * d + hd * DK + NDB * 4 * h;
+    float* dst = out + ((size_t)b * S + q) * d + hd * DK + 4 * h;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int k = 0; k < NDB; ++k) {
+      for (int pj = 0; pj < NDB; ++pj) {
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = o[(4 * k + e) % NDB][4 * u + (4 * k + e) / NDB] * inv;
-        *reinterpret_cast<f32x4*>(dst + NDB * 8 * u + 4 * k) = v;
+        for (int e = 0; e < 4; ++e) v[e] = o[e % NDB][4 * u + pj * JP + e / NDB] * inv;
+        *reinterpret_cast<f32x4*>(dst + 8 * NDB * u + 8 * pj) = v;
       }
   }
 #endif
