@@ -386,7 +386,7 @@ hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) {
   if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400) {
     auto fill = [](long n) { return (double)n / (double)(((n + 255) / 256) * 256); };  // of the last round, one workgroup per CU
     const long c256 = wgs((p.M + 255) / 256, 256), c128 = wgs((p.M + 127) / 128, 256);
-    if (c256 >= 200 && fill(c256) >= 0.95) return launch_t<256, 256, 32, 1, 8, 2>(p, st);
+    if (c256 >= 200 && c256 <= 512 && fill(c256) >= 0.95) return launch_t<256, 256, 32, 1, 8, 2>(p, st);  // measured for one and two rounds only
     if (c128 <= 512 && fill(c128) >= 0.95) return launch_t<128, 256, 32, 1, 4, 4>(p, st);
   }
   if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400) return launch_t<64, 256, 32, 1, 2, 4>(p, st);
