@@ -22,6 +22,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+def rank_env(env) -> None:
+    """Environment every rank of a multi-process run needs, set BEFORE torch (and with it HIP / RCCL) is imported — in the
+    ranks themselves, so that it holds for BOTH launch forms (`python bench.py --gpus N` re-executing itself, and the
+    driver's `python -m torch.distributed.run ... bench.py`, which never passes through self_launch):
+    * HSA_ENABLE_IPC_MODE_LEGACY=0: this host driver only supports dmabuf IPC; without it RCCL init / cross-process device
+      memory fails with `hipIpcGetMemHandle: invalid argument`;
+    * OMP_NUM_THREADS: N ranks x (all host cores) torch-CPU threads would oversubscribe the host (rank 0 also runs the
+      CPU-oracle leg at N = 1, where the default stays untouched)."""
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if int(env.get("WORLD_SIZE", "1")) > 1:
+        env.setdefault("OMP_NUM_THREADS", "8")
+
+
+rank_env(os.environ)
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -43,8 +59,9 @@ def self_launch(n_gpus: int) -> int:
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL / cross-process device memory need it on this driver
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (the ranks set it themselves too: rank_env)
     env.setdefault("OMP_NUM_THREADS", "8")
+    env["NS_BENCH_LAUNCHER"] = "self"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
@@ -183,6 +200,10 @@ def main():
     T_pad = int(out[0].shape[1])
     stats = torch.tensor([elapsed, float(frames), float(T_pad)], dtype=torch.float64, device=dev)
     devices = [{"rank": rank, "device": f"cuda:{dev_index}", "name": torch.cuda.get_device_name(dev)}]
+    # per-rank view (SURVEY.md §8e "scaling risks": per-shard T_pad differs, so load imbalance must be visible in a SCALE line)
+    per_rank = [{"rank": rank, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "T_pad": T_pad, "valid_frames": frames,
+                 "hsa_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "omp_num_threads": os.environ.get("OMP_NUM_THREADS"),
+                 "launcher": os.environ.get("NS_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "none")}]
     world_seen = 1
     if dist is not None:
         tmax = stats.clone()
@@ -192,8 +213,9 @@ def main():
         elapsed_max, frames_total, T_pad_max = float(tmax[0]), float(tsum[1]), int(tmax[2])
         world_seen = dist.get_world_size()  # what the process group (RCCL on the GPU box) itself reports
         gathered = [None] * world
-        dist.all_gather_object(gathered, devices[0])
-        devices = gathered
+        dist.all_gather_object(gathered, (devices[0], per_rank[0]))
+        devices = [g[0] for g in gathered]
+        per_rank = [g[1] for g in gathered]
     else:
         elapsed_max, frames_total, T_pad_max = elapsed, float(frames), T_pad
 
@@ -224,7 +246,7 @@ def main():
         "metric": "mel_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16x3" if b3 else "f32", "data": "synthetic",
-        "devices": devices, "backend": backend, "world_size_seen_by_rccl": world_seen, "one_gpu_rig": one_gpu,
+        "devices": devices, "backend": backend, "world_size_seen_by_rccl": world_seen, "one_gpu_rig": one_gpu, "per_rank": per_rank,
         "config": {"workload": f"{args.workload}{'_bf16x3' if b3 else ''}{' (ragged lengths)' if args.ragged else ''}: LJSpeech config, batch {B_shard}/GPU x {args.gpus} GPU, phoneme_len {L}, "
                                f"T_pad {T_pad_max}, d_model {cfg['transformer']['decoder_hidden']}, "
                                f"{cfg['transformer']['encoder_layer']}+{cfg['transformer']['decoder_layer']} FFT layers, "

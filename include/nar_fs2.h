@@ -66,6 +66,10 @@ int ns_bind_arena(ns_model* m, void* dev_arena, size_t bytes);
  * "mel_encoder.*" keys and "*.num_batches_tracked" are accepted and ignored (returns 0);
  * any other unknown key or a shape mismatch is an error. */
 int ns_set_weight(ns_model* m, const char* name, const float* host, const int64_t* shape, int ndim);
+/* The same key / rank / shape validation WITHOUT touching the model (nothing staged, a loaded model stays loaded):
+ * load_state_dict() checks every entry with this first, so that a rejected state dict leaves the previous weights in use
+ * (nn.Module.load_state_dict raises before/without corrupting the module, utils/model.py:21-22). */
+int ns_check_weight(ns_model* m, const char* name, const int64_t* shape, int ndim);
 /* After the last ns_set_weight: repack (conv [out,in,k] -> [out,k,in]; fused QKV), fold eval-mode
  * BatchNorm into the PostNet convs, upload into the arena.  Fails if an inference key is missing. */
 int ns_finalize_weights(ns_model* m, void* stream);
@@ -95,13 +99,21 @@ int ns_forward_durations(ns_model* m, const int64_t* texts, const int64_t* src_l
                          int64_t* mel_lens_host, void* stream);
 
 /* Phase 2: LengthRegulator + frame-level pitch/energy + MelDecoder + mel_linear + PostNet (+ residual).
- * T must be max(mel_lens) (or a caller-chosen max_mel_len >= it, model/modules.py:128-129 semantics).
- * Writes mel [B,T,n_mel], postnet_mel [B,T,n_mel], p_pred [B,T], e_pred [B,T], mel_mask [B,T]. */
+ * T is max(mel_lens), or a caller-chosen capacity (max_mel_len, model/modules.py:128-131,204-213 semantics: the mel axis is
+ * padded and masked to it).  mel_lens stays on the device: a caller that fixes T up front can enqueue this call right
+ * behind ns_forward_durations with NO host read in between (capacity mode).
+ * Writes mel [B,T,n_mel], postnet_mel [B,T,n_mel], p_pred [B,T], e_pred [B,T], mel_mask [B,T] and
+ * status [B] (int32, device or pinned host memory, REQUIRED): per utterance a bit set of
+ *   NS_STATUS_TRUNCATED  mel_lens[b] > T: the frames past T were cut off (the rest of the row is still well defined)
+ *   NS_STATUS_BAD_TOKEN  phase 1 reported a token id outside [0, n_vocab) for this utterance (mel_lens[b] = -1)
+ * so that neither condition can pass silently when the caller never reads mel_lens before this call. */
+#define NS_STATUS_TRUNCATED 1
+#define NS_STATUS_BAD_TOKEN 2
 /* p_targets / e_targets ([B,T], nullable): forward()'s p_targets / e_targets — when given, the embedding is
  * taken from bucketize(target) and the prediction is returned unscaled (model/modules.py:82-84,93-95). */
 int ns_forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens, float p_control, float e_control,
                    const float* p_targets, const float* e_targets, const void* ws_enc, void* ws_dec, size_t ws_dec_bytes,
-                   float* mel, float* postnet_mel, float* p_pred, float* e_pred, uint8_t* mel_mask, void* stream);
+                   float* mel, float* postnet_mel, float* p_pred, float* e_pred, uint8_t* mel_mask, int32_t* status, void* stream);
 
 /* ---- per-operator entry points (the rows of SURVEY.md §8a; used by the parity tests and by bench.py's
  *      dominant-kernel timing).  `prefix` is the reference module path, e.g.

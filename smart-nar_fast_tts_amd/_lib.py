@@ -34,12 +34,14 @@ SIGNATURES = {
     "ns_arena_bytes": (_Z, [_P]),
     "ns_bind_arena": (_I, [_P, _P, _Z]),
     "ns_set_weight": (_I, [_P, _S, _P, C.POINTER(C.c_int64), _I]),
+    "ns_check_weight": (_I, [_P, _S, C.POINTER(C.c_int64), _I]),
     "ns_finalize_weights": (_I, [_P, _P]),
     "ns_adopt_arena": (_I, [_P]),
     "ns_encoder_ws_bytes": (_Z, [_P, _I, _I]),
     "ns_decoder_ws_bytes": (_Z, [_P, _I, _I, _I]),
     "ns_forward_durations": (_I, [_P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "ns_forward_mel": (_I, [_P, _I, _I, _I, _P, _F, _F, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P]),
+    "ns_forward_mel": (_I, [_P, _I, _I, _I, _P, _F, _F, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _P]),
+
     "ns_op_ws_bytes": (_Z, [_P, _I, _I]),
     "ns_op_mask_from_lengths": (_I, [_P, _I, _I, _P, _P]),
     "ns_op_sinusoid_table": (_I, [_I, _I, _P, _P]),
@@ -63,6 +65,8 @@ SIGNATURES = {
     "ns_profile_read": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ns_profile_read_slot": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
+
+STATUS_TRUNCATED, STATUS_BAD_TOKEN = 1, 2  # include/nar_fs2.h NS_STATUS_*
 
 _lib = None
 

@@ -196,7 +196,7 @@ extern "C" int ns_bind_arena(ns_model* m, void* dev, size_t bytes) {
 
 extern "C" int ns_adopt_arena(ns_model* m) {
   if (!m || !m->arena) return fail("ns_adopt_arena: no arena bound");
-  m->staged.clear();
+  for (auto& kv : m->staged) { kv.second.data.clear(); kv.second.data.shrink_to_fit(); kv.second.set = false; }
   m->ready = true;
   return 0;
 }
@@ -206,26 +206,43 @@ static bool ends_with(const std::string& s, const char* p) {
   size_t n = strlen(p); return s.size() >= n && s.compare(s.size() - n, n, p) == 0;
 }
 
-extern "C" int ns_set_weight(ns_model* m, const char* name_c, const float* host, const int64_t* shape, int ndim) {
-  if (!m || !name_c) return fail("ns_set_weight: null argument");
+// name / rank / shape validation shared by ns_check_weight (no side effect) and ns_set_weight; *slot = nullptr for an ignored key
+static int lookup_weight(ns_model* m, const char* name_c, const int64_t* shape, int ndim, Staged** slot, size_t* count, const char* who) {
+  *slot = nullptr;
+  if (!m || !name_c) return fail(std::string(who) + ": null argument");
   std::string name(name_c);
   // training-only aligner weights live in every checkpoint; accept and ignore
   if (starts_with(name, "mel_encoder.") || ends_with(name, ".num_batches_tracked")) return 0;
   auto it = m->staged.find(name);
-  if (it == m->staged.end()) return fail("ns_set_weight: unexpected key '" + name + "'");
+  if (it == m->staged.end()) return fail(std::string(who) + ": unexpected key '" + name + "'");
   Staged& s = it->second;
-  if ((int)s.shape.size() != ndim) return fail("ns_set_weight: rank mismatch for '" + name + "'");
+  if ((int)s.shape.size() != ndim) return fail(std::string(who) + ": rank mismatch for '" + name + "'");
+  if (ndim > 0 && !shape) return fail(std::string(who) + ": null shape for '" + name + "'");
   size_t n = 1;
   for (int i = 0; i < ndim; ++i) {
     if (shape[i] != s.shape[i]) {
-      return fail("ns_set_weight: size mismatch for '" + name + "': dim " + std::to_string(i) + " is " +
+      return fail(std::string(who) + ": size mismatch for '" + name + "': dim " + std::to_string(i) + " is " +
                   std::to_string(shape[i]) + ", expected " + std::to_string(s.shape[i]));
     }
     n *= (size_t)shape[i];
   }
-  if (!host) return fail("ns_set_weight: null data for '" + name + "'");
-  s.data.assign(host, host + n);
-  s.set = true;
+  *slot = &s;
+  *count = n;
+  return 0;
+}
+
+extern "C" int ns_check_weight(ns_model* m, const char* name, const int64_t* shape, int ndim) {
+  Staged* s; size_t n;
+  return lookup_weight(m, name, shape, ndim, &s, &n, "ns_check_weight");
+}
+
+extern "C" int ns_set_weight(ns_model* m, const char* name_c, const float* host, const int64_t* shape, int ndim) {
+  Staged* s; size_t n;
+  NS_TRY(lookup_weight(m, name_c, shape, ndim, &s, &n, "ns_set_weight"));
+  if (!s) return 0;
+  if (!host) return fail(std::string("ns_set_weight: null data for '") + name_c + "'");
+  s->data.assign(host, host + n);
+  s->set = true;
   m->ready = false;
   return 0;
 }
@@ -350,9 +367,20 @@ struct Bump {
   }
 };
 
+// ticket counters of one forward phase (gemm_conv.hip TICKET, attention.hip): zeroed as a block by the phase's first kernel,
+// every ticketed launch then takes its own slice — no reset, no reuse inside a phase
+constexpr int TICKET_INTS = 16384;
+
 struct Scratch {  // per-stack temporaries for M rows
   float *xa, *xb, *qkv, *att, *t1, *x1, *hid, *vp1, *vp2, *pos_ext, *att_part;
   size_t att_part_floats;
+  int* tickets; int tickets_used;
+  int* take_tickets(int n) {  // nullptr when the block is spent (the caller then takes the two-launch form)
+    if (!tickets || tickets_used + n > TICKET_INTS) return nullptr;
+    int* t = tickets + tickets_used;
+    tickets_used += n;
+    return t;
+  }
 };
 
 static size_t imax(size_t a, size_t b) { return a > b ? a : b; }
@@ -371,6 +399,8 @@ static Scratch carve(const ns_config& c, Bump& bp, size_t M, int S) {
   const size_t qtiles = ((size_t)S + 127) / 128;
   s.att_part_floats = (M / (size_t)S) * qtiles * hmin < ATT_SPLIT_MAX_BLOCKS ? ATT_SPLIT_MAX * (M * d + 2 * M * hmax) : 0;
   s.att_part = s.att_part_floats ? bp.f(s.att_part_floats) : nullptr;
+  s.tickets = (int*)bp.raw(TICKET_INTS * sizeof(int));
+  s.tickets_used = 0;
   return s;
 }
 }  // namespace
@@ -429,15 +459,25 @@ static bool fuse_row_epilogue(int M, int N, int Cin) {
   return conv_gemm_row_epilogue_ok(M, N, Cin) && (M + 31) / 32 >= 200;
 }
 
-// Y = mask(LayerNorm(act(conv(X)) + resid)): one launch when the full-row tile applies, else GEMM -> tmp -> k_layernorm
+// Y = mask(LayerNorm(act(conv(X)) + resid)) in ONE launch: the full-row tile when the launch is large enough, else the
+// small-grid ladder with the ticketed row epilogue (raw rows through tmp, the last workgroup of a row block normalises it).
+// Two launches (GEMM -> tmp -> k_layernorm) only in the opt-in bf16x3 mode for widths its LayerNorm tile does not cover,
+// or when the phase's ticket block is spent.
 static int gemm_ln(const float* X, int ldx, const float* W, const float* bias, const float* resid, float* tmp, float* Y,
                    int M, int N, int Cin, int KW, int S, int act, const float* g, const float* b, const long long* lens,
-                   hipStream_t st, const unsigned short* Wb3 = nullptr) {
-  if (fuse_row_epilogue(M, N, Cin)) {
-    RowEpilogue e;
-    memset(&e, 0, sizeof(e));
-    e.ln_g = g; e.ln_b = b; e.lens = lens;
-    return gemm(X, ldx, W, bias, resid, N, Y, N, M, N, Cin, KW, S, act, st, &e, EPI_LN, Wb3);
+                   Scratch& sc, hipStream_t st, const unsigned short* Wb3 = nullptr) {
+  RowEpilogue e;
+  memset(&e, 0, sizeof(e));
+  e.ln_g = g; e.ln_b = b; e.lens = lens;
+  if (Wb3 && !conv_gemm_b3_ok(M, N, Cin, KW, EPI_LN) && conv_gemm_b3_ok(M, N, Cin, KW, EPI_NONE)) {
+    NS_TRY(gemm(X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st, nullptr, EPI_NONE, Wb3));
+    NS_HIP(launch_layernorm(tmp, g, b, Y, M, N, S, lens, st));
+    return 0;
+  }
+  if (fuse_row_epilogue(M, N, Cin)) return gemm(X, ldx, W, bias, resid, N, Y, N, M, N, Cin, KW, S, act, st, &e, EPI_LN, Wb3);
+  if (Cin % 32 == 0 && N % 4 == 0 && N <= 1024 && (e.ticket = sc.take_tickets(conv_gemm_ticket_ints(M))) != nullptr) {
+    e.y_out = Y;
+    return gemm(X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st, &e, EPI_LN);
   }
   NS_TRY(gemm(X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st));
   NS_HIP(launch_layernorm(tmp, g, b, Y, M, N, S, lens, st));
@@ -481,11 +521,12 @@ static int mha(const ns_model* m, const LayerW& L, int d, int H, const float* x,
   {
     ProfScope ps(m, 1, st, 4.0 * (double)M * (double)S * (double)d);
     NS_TRY(ps.begin());
-    NS_HIP(launch_attention(sc.qkv, lens, B, S, H, d / H, sc.att, sc.att_part, sc.att_part_floats, st));
+    NS_HIP(launch_attention(sc.qkv, lens, B, S, H, d / H, sc.att, sc.att_part, sc.att_part_floats,
+                            sc.att_part ? sc.take_tickets(attention_ticket_ints(B, S, H)) : nullptr, st));
     NS_TRY(ps.end());
   }
   return gemm_ln(sc.att, d, m->P(L.fc_w), m->P(L.fc_b), x, sc.t1, out, M, d, d, 1, S, ACT_NONE, m->P(L.ln1_g), m->P(L.ln1_b),
-                 mask_rows ? lens : nullptr, st, b3(L.fc_b3));
+                 mask_rows ? lens : nullptr, sc, st, b3(L.fc_b3));
 }
 
 // PositionwiseFeedForward.forward (transformer/SubLayers.py:87-95)
@@ -501,7 +542,7 @@ static int ffn(const ns_model* m, const LayerW& L, int d, const float* x, const 
     NS_TRY(ps.end());
   }
   return gemm_ln(sc.hid, c.d_inner, m->P(L.w2), m->P(L.w2_b), x, sc.t1, out, M, d, c.d_inner, c.ffn_k2, S, ACT_NONE, m->P(L.ln2_g),
-                 m->P(L.ln2_b), mask_rows ? lens : nullptr, st,
+                 m->P(L.ln2_b), mask_rows ? lens : nullptr, sc, st,
                  L.w2_b3 != NO_B3 ? reinterpret_cast<const unsigned short*>(m->P(L.w2_b3)) : nullptr);
 }
 
@@ -533,17 +574,18 @@ static int predictor(const ns_model* m, const PredW& w, const float* x, const lo
   const int M = B * S, F = c.vp_filter;
   // conv1d_1 -> relu -> layer_norm_1 (no mask between the layers: model/modules.py:245-274)
   NS_TRY(gemm_ln(x, w.cin, m->P(w.c1), m->P(w.c1_b), nullptr, sc.vp1, sc.vp2, M, F, w.cin, c.vp_kernel, S, ACT_RELU, m->P(w.ln1_g),
-                 m->P(w.ln1_b), nullptr, st));
+                 m->P(w.ln1_b), nullptr, sc, st));
   // conv1d_2 -> relu -> layer_norm_2 -> linear -> mask (-> bucketize + embedding add): the whole tail rides on conv1d_2's
-  // full-row epilogue when that tile applies
-  if (fuse_row_epilogue(M, F, F)) {
-    RowEpilogue e;
-    memset(&e, 0, sizeof(e));
-    e.ln_g = m->P(w.ln2_g); e.ln_b = m->P(w.ln2_b); e.lens = lens; e.wlin = m->P(w.lin_w); e.blin = m->P(w.lin_b); e.pred = pred;
-    e.control = control; e.target = target; e.bins = bins; e.n_edges = c.n_bins - 1; e.emb = emb; e.x_in = x; e.pos = pos; e.x_out = x_out;
-    e.D = w.cin;
+  // row epilogue — the full-row tile when the launch is large, the ticketed form on small grids
+  RowEpilogue e;
+  memset(&e, 0, sizeof(e));
+  e.ln_g = m->P(w.ln2_g); e.ln_b = m->P(w.ln2_b); e.lens = lens; e.wlin = m->P(w.lin_w); e.blin = m->P(w.lin_b); e.pred = pred;
+  e.control = control; e.target = target; e.bins = bins; e.n_edges = c.n_bins - 1; e.emb = emb; e.x_in = x; e.pos = pos; e.x_out = x_out;
+  e.D = w.cin;
+  if (fuse_row_epilogue(M, F, F))
     return gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, nullptr, F, M, F, F, c.vp_kernel, S, ACT_RELU, st, &e, EPI_LN_PRED);
-  }
+  if (F % 32 == 0 && F <= 1024 && (e.ticket = sc.take_tickets(conv_gemm_ticket_ints(M))) != nullptr)
+    return gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st, &e, EPI_LN_PRED);
   NS_TRY(gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st));
   NS_HIP(launch_ln_linear_embed(sc.vp1, m->P(w.ln2_g), m->P(w.ln2_b), m->P(w.lin_w), m->P(w.lin_b), pred, M, F, S, lens,
                                 control, target, bins, c.n_bins, emb, x, pos, x_out, w.cin, st));
@@ -582,7 +624,7 @@ static int encoder(const ns_model* m, const long long* texts, const long long* l
   const float* pos;
   NS_TRY(position_rows(m, m->enc_pos, L, d, sc, &pos, st));
   float* cur = m->enc.empty() ? out : sc.xa;
-  NS_HIP(launch_embed_pos(texts, m->P(m->emb), pos, cur, M, L, d, c.n_vocab, st));
+  NS_HIP(launch_embed_pos(texts, m->P(m->emb), pos, cur, M, L, d, c.n_vocab, sc.tickets, TICKET_INTS, st));  // + zeroes the phase's tickets
   for (size_t i = 0; i < m->enc.size(); ++i) {
     float* dst = (i + 1 == m->enc.size()) ? out : (cur == sc.xa ? sc.xb : sc.xa);
     NS_TRY(fft_block(m, m->enc[i], d, c.n_enc_head, cur, lens, B, L, dst, sc, st));
@@ -645,10 +687,18 @@ extern "C" int ns_forward_durations(ns_model* m, const int64_t* texts, const int
 extern "C" int ns_forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens, float p_control, float e_control,
                               const float* p_targets, const float* e_targets,
                               const void* ws_enc, void* ws_dec, size_t ws_bytes, float* mel, float* postnet_mel, float* p_pred,
-                              float* e_pred, uint8_t* mel_mask, void* stream) {
+                              float* e_pred, uint8_t* mel_mask, int32_t* status, void* stream) {
   NS_TRY(check_ready(m));
   if (B <= 0 || L <= 0) return fail("ns_forward_mel: empty batch");
-  if (T <= 0) return 0;  // all durations zero: [B,0,*] outputs, nothing to launch
+  if (!status) return fail("ns_forward_mel: status [B] is required (a T smaller than an utterance's length must not go unnoticed)");
+  if (T < 0) return fail("ns_forward_mel: negative T");
+  if (T == 0) {  // all durations zero: [B,0,*] outputs; only the status words (an utterance with frames would be cut off entirely)
+    Bump be0(const_cast<void*>(ws_enc), (size_t)-1);
+    be0.f((size_t)B * L * m->cfg.d_enc);
+    const int32_t* cum0 = (const int32_t*)be0.raw((size_t)B * L * sizeof(int32_t));
+    NS_HIP(launch_length_regulate(nullptr, cum0, B, L, m->cfg.d_enc, 0, nullptr, nullptr, (const long long*)mel_lens, status, nullptr, 0, (hipStream_t)stream));
+    return 0;
+  }
   if (ws_bytes < ns_decoder_ws_bytes(m, B, L, T)) return fail("ns_forward_mel: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const ns_config& c = m->cfg;
@@ -666,9 +716,9 @@ extern "C" int ns_forward_mel(ns_model* m, int B, int L, int T, const int64_t* m
     // extension: GaussianUpsampling (model/modules.py:166-192) in the LengthRegulator's place;
     // mel_len = sum of the rounded durations, frames past an utterance's own length are zero like pad()'s
     if ((size_t)B * (L + 1) > (size_t)M * c.vp_filter) return fail("ns_forward_mel: workspace too small for the Gaussian centres");
-    NS_HIP(launch_gaussian_upsampling(enc_out, dur_keep, B, L, c.d_enc, T, T, sc.xa, sc.vp2, nullptr, lens, st));
+    NS_HIP(launch_gaussian_upsampling(enc_out, dur_keep, B, L, c.d_enc, T, T, sc.xa, sc.vp2, nullptr, lens, status, sc.tickets, TICKET_INTS, st));
   } else {
-    NS_HIP(launch_length_regulate(enc_out, cum, B, L, c.d_enc, T, sc.xa, mel_mask, st));  // + the mel mask
+    NS_HIP(launch_length_regulate(enc_out, cum, B, L, c.d_enc, T, sc.xa, mel_mask, lens, status, sc.tickets, TICKET_INTS, st));  // + mel mask, status, ticket zeroing
   }
   const float* pos;
   NS_TRY(position_rows(m, m->dec_pos, T, d, sc, &pos, st));
@@ -725,7 +775,8 @@ static int find_layer(ns_model* m, const char* prefix_c, const LayerW** L, int* 
   if (ws_bytes < ns_op_ws_bytes(m, (B_), (S_))) return fail("workspace too small");   \
   hipStream_t st = (hipStream_t)stream;                                               \
   Bump bp(ws, ws_bytes);                                                              \
-  Scratch sc = carve(m->cfg, bp, (size_t)(B_) * (S_), (S_));
+  Scratch sc = carve(m->cfg, bp, (size_t)(B_) * (S_), (S_));                          \
+  NS_HIP(hipMemsetAsync(sc.tickets, 0, TICKET_INTS * sizeof(int), st)); /* a forward's first kernel does this itself */
 
 extern "C" int ns_op_mask_from_lengths(const int64_t* lens, int B, int max_len, uint8_t* mask, void* stream) {
   NS_HIP(launch_mask_from_lengths((const long long*)lens, B, max_len, mask, (hipStream_t)stream));
@@ -783,7 +834,7 @@ extern "C" int ns_op_duration_scan(const float* d_rounded, int B, int L, int32_t
   return 0;
 }
 extern "C" int ns_op_length_regulate(const float* x, const int32_t* cum, int B, int L, int D, int T, float* out, void* stream) {
-  NS_HIP(launch_length_regulate(x, cum, B, L, D, T, out, nullptr, (hipStream_t)stream));
+  NS_HIP(launch_length_regulate(x, cum, B, L, D, T, out, nullptr, nullptr, nullptr, nullptr, 0, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ns_op_variance_embedding(ns_model* m, int which, const float* x, const int64_t* lens, int B, int S, float control,
@@ -828,7 +879,7 @@ extern "C" int ns_op_bucketize(const float* values, int n, const float* bins, in
 extern "C" int ns_op_gaussian_upsampling(const float* x, const float* durations, int B, int L, int D, int T, int T_out, float* out,
                                          float* s, float* w, void* stream) {
   if (T_out < T) return fail("ns_op_gaussian_upsampling: T_out < T");
-  NS_HIP(launch_gaussian_upsampling(x, durations, B, L, D, T, T_out, out, s, w, nullptr, (hipStream_t)stream));
+  NS_HIP(launch_gaussian_upsampling(x, durations, B, L, D, T, T_out, out, s, w, nullptr, nullptr, nullptr, 0, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ns_op_mel_decoder(ns_model* m, const float* x, const int64_t* lens, int B, int T, float* out, void* ws,
@@ -851,8 +902,18 @@ extern "C" int ns_op_postnet(ns_model* m, const float* mel, int B, int T, float*
 }
 extern "C" int ns_op_attention_core(const float* qkv, const int64_t* lens, int B, int S, int H, int dk, float* out, void* scratch,
                                     size_t scratch_bytes, void* stream) {
-  NS_HIP(launch_attention(qkv, (const long long*)lens, B, S, H, dk, out, (float*)scratch, scratch_bytes / sizeof(float),
-                          (hipStream_t)stream));
+  // the strip kernel's tickets are carved from the END of the caller's scratch and zeroed here (a forward's opening kernel
+  // does that for its own launches)
+  float* sp = (float*)scratch;
+  size_t floats = scratch_bytes / sizeof(float);
+  int* tickets = nullptr;
+  const size_t tk = ((size_t)attention_ticket_ints(B, S, H) + 63) & ~(size_t)63;
+  if (sp && B > 0 && S > 0 && floats > tk) {
+    floats -= tk;
+    tickets = (int*)(sp + floats);
+    NS_HIP(hipMemsetAsync(tickets, 0, tk * sizeof(int), (hipStream_t)stream));
+  }
+  NS_HIP(launch_attention(qkv, (const long long*)lens, B, S, H, dk, out, sp, floats, tickets, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ns_op_ffn_conv1(ns_model* m, const char* prefix, const float* x, int B, int S, float* hidden, void* stream) {

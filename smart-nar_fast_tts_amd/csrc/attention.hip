@@ -59,9 +59,6 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   // tiles of one (batch, head) are consecutive workgroups, i.e. they land on 8 DIFFERENT XCDs and every XCD pulls that
   // head's K and V through its own L2 (profiles/r02: 4.5x the algorithmic bytes at config 2).  Handing XCD x the x-th
   // contiguous slice of the (batch, head, query tile) order instead keeps all query tiles of a head on one L2.
-#if defined(NS_LAB_ATT_NOREMAP)
-  const int bx = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
-#else
   int bx, hd, b;
   {
     const int nx = gridDim.x, ny = gridDim.y, nblk = nx * ny * gridDim.z;
@@ -72,7 +69,6 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     hd = (pos / nx) % ny;
     b = pos / (nx * ny);
   }
-#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, qi = lane & 31;
@@ -116,13 +112,26 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)&Vd[(wid * NI + i) * RPI * DK], 16, vv[i] + (t0 + kt) * tile_step, 0, 0, 0);
   };
 
+  // the first tiles are requested before anything else, so that their round trip runs under the Q loads
+  if (nkt > 0) {
+    dma_k(Ks0, 0);
+    dma_v(Vs0, 0);
+    if (nkt > 1) dma_k(Ks1, 1);
+  }
+
   // Q^T operand: lane (q, h) keeps Q[q][8g + 4h + e], pre-multiplied by log2(e)/sqrt(d_k) so the scores come out
   // of the MFMA already scaled into the exp2 domain (one multiply per Q element instead of one per score)
   f32x4 qreg[NG];
+  {
+    // all NG loads in flight together, no branch: a row past S reads row S-1 instead and is scaled by zero (it is never
+    // stored).  With `if (q < S)` around each load hipcc emitted load -> s_waitcnt vmcnt(0) NG times in a row — 16 serialized
+    // round trips (~10 us) at the head of every workgroup, ahead of the first K / V DMA.
+    const float* qrow = base + (size_t)(q < S ? q : S - 1) * ld + 4 * h;
+    const float qs = q < S ? c_scale : 0.f;
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    if (q < S) qreg[g] = *reinterpret_cast<const f32x4*>(base + (size_t)q * ld + 8 * g + 4 * h) * c_scale;
-    else qreg[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < NG; ++g) qreg[g] = *reinterpret_cast<const f32x4*>(qrow + 8 * g);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) qreg[g] *= qs;
   }
 
   f32x16 o[NDB];
@@ -219,11 +228,6 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     }
   };
 
-  if (nkt > 0) {
-    dma_k(Ks0, 0);
-    dma_v(Vs0, 0);
-    if (nkt > 1) dma_k(Ks1, 1);
-  }
   __syncthreads();
 
   f32x16 s_a, s_b;  // score tiles of even / odd key tiles (static roles in the 2x unrolled loop: no register copies)
@@ -291,6 +295,264 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Small grids (single-utterance latency, the encoder's S <= 128): k_attention_strip.  Same arithmetic as k_attention — the
+// same S^T = K Q^T / online softmax / O^T += V^T P^T per 32-key tile — with the roles in the workgroup swapped: the four
+// waves share ONE strip of 32 queries and each sweeps its own contiguous range of key tiles through its own K / V buffers
+// (no barrier in the loop; a wave is alone on its SIMD), then the four (O, m, l) partials are merged through LDS.  A launch
+// therefore has S/32 x H x B workgroups instead of S/128 x H x B, and up to `nsplit` of them share a strip's key axis; their
+// partials meet in memory and the LAST one to arrive (one ticket per strip, cdna_hip_programming.md Guideline 16 counter
+// form: write-through stores, vmcnt drain, barrier, relaxed agent fetch_add / one agent acquire) merges them in split order.
+// This replaces split-key k_attention + k_attention_merge on such launches (one launch instead of two, a quarter of the
+// partial bytes) and removes the merge launch altogether when nsplit == 1 (the encoder).
+// Merging, in-workgroup and across workgroups alike: out = sum_i O_i 2^(m_i - m) / sum_i l_i 2^(m_i - m), m = max_i m_i,
+// i in key order — exact for any split (each partial is an exact softmax numerator / denominator relative to its own m_i).
+template <int DK>
+__global__ __launch_bounds__(256) void k_attention_strip(const float* __restrict__ qkv, const long long* __restrict__ lens,
+                                                          int S, int d, float c_scale, float* __restrict__ out, int nsplit,
+                                                          float* __restrict__ opart, float* __restrict__ mlpart,
+                                                          int* __restrict__ tickets) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BC = 32, CPR = DK / 4, RPI = 64 / CPR;
+  constexpr int NI = (BC * CPR) / 64;  // DMA instructions per tile: ONE wave fills its own tile
+  constexpr int NG = DK / 8, NDB = DK / 32;
+  constexpr int FSH = (DK == 32) ? 1 : 0, FMSK = (DK == 32) ? 7 : 15;
+  constexpr int JP = 4 / NDB;
+  static_assert(DK == 32 || DK == 64 || DK == 128, "d_k");
+  // one K and one V tile PER WAVE (wave-private: the loop needs no barrier); the compiler tracks LDS-DMA per LDS object, so a
+  // read of Ks only waits for the DMAs into Ks.  After the sweep the K region holds the wave's O^T partial, V's head its (m, l).
+  __shared__ __attribute__((aligned(16))) float Ks[4 * BC * DK];
+  __shared__ __attribute__((aligned(16))) float Vs[4 * BC * DK];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, qi = lane & 31;
+  const int nstrips = gridDim.x / nsplit;
+  const int strip = blockIdx.x / nsplit, sp = blockIdx.x - strip * nsplit;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int q = strip * 32 + qi;
+  const int ld = 3 * d;
+  const float* base = qkv + (size_t)b * S * ld + hd * DK;
+  const long long len_ll = lens ? lens[b] : (long long)S;
+  const int len = (int)(len_ll < S ? len_ll : S);
+  const int nkt_all = (len + BC - 1) / BC;
+  const int nranges = nsplit * 4;                        // key ranges of this strip, in key order: range = sp * 4 + wave
+  const int tpr = (nkt_all + nranges - 1) / nranges;     // key tiles per range
+  const int t0 = (sp * 4 + wid) * tpr;
+  const int nkt = max(0, min(nkt_all, t0 + tpr) - t0);
+
+  const int nrec = ((S - 1) * ld + DK) * 4;
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(base + d), (short)0, nrec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(base + 2 * d), (short)0, nrec, 0x00020000);
+  float* const Kw = Ks + wid * BC * DK;
+  float* const Vw = Vs + wid * BC * DK;
+  const int lr = lane / CPR, ls = lane % CPR;
+  const int tile_step = BC * ld * 4;
+  auto dma_k = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = i * RPI + lr;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)&Kw[i * RPI * DK], 16, (r * ld + ((ls ^ ((r >> FSH) & FMSK)) * 4)) * 4 + (t0 + kt) * tile_step, 0, 0, 0);
+    }
+  };
+  auto dma_v = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = i * RPI + lr;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)&Vw[i * RPI * DK], 16, (r * ld + ls * 4) * 4 + (t0 + kt) * tile_step, 0, 0, 0);
+    }
+  };
+  if (nkt > 0) { dma_k(0); dma_v(0); }
+
+  f32x4 qreg[NG];
+  {
+    // all NG loads in flight together, no branch: a row past S reads row S-1 instead and is scaled by zero (it is never
+    // stored).  With `if (q < S)` around each load hipcc emitted load -> s_waitcnt vmcnt(0) NG times in a row — 16 serialized
+    // round trips (~10 us) at the head of every workgroup, ahead of the first K / V DMA.
+    const float* qrow = base + (size_t)(q < S ? q : S - 1) * ld + 4 * h;
+    const float qs = q < S ? c_scale : 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) qreg[g] = *reinterpret_cast<const f32x4*>(qrow + 8 * g);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) qreg[g] *= qs;
+  }
+  f32x16 o[NDB];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  int koff[NG];
+  {
+    const int f = (qi >> FSH) & FMSK;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) koff[g] = qi * DK + (((2 * g + h) ^ f) * 4);
+  }
+  auto row_label = [](int i) { return (i & ~7) + ((i & 3) / JP) * (2 * JP) + ((i >> 2) & 1) * JP + (i & 3) % JP; };
+  const float* vp = Vw + (4 * h) * DK + NDB * row_label(qi);
+
+  // the per-tile arithmetic below is k_attention's, statement for statement (see there for the layout argument)
+  // DMA completion is waited for by hand (in-order vmcnt): ahead of the scores K(kt) must have landed while V(kt), issued after
+  // it, may still fly; ahead of P V the tile V(kt) must have landed while K(kt+1), issued after it, may still fly
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+    f32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const f32x4 kf = *reinterpret_cast<const f32x4*>(Kw + koff[g]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qreg[g][e], sc, 0, 0, 0);
+    }
+    if (kt + 1 < nkt) {  // K(kt) is consumed (its fragment reads returned before the MFMAs issued): refill it under the softmax
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      dma_k(kt + 1);
+    }
+    if ((t0 + kt) * BC + BC > len) {
+      const int kbase = (t0 + kt) * BC + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kbase + (r & 3) + 8 * (r >> 2);
+        sc[r] = key < len ? sc[r] : -INFINITY;
+      }
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sc[r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    constexpr float RESCALE_LOG2 = 10.f;
+    const bool need = mt > m_run + RESCALE_LOG2;
+    const float m_new = need ? mt : m_run;
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = need ? __builtin_amdgcn_exp2f(m_run - m_use) : 1.0f;
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_use);
+      psum += sc[r];
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
+    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      typedef float vrow_t __attribute__((ext_vector_type(NDB)));
+      const vrow_t vv = *reinterpret_cast<const vrow_t*>(vp + ((r & 3) + 8 * (r >> 2)) * DK);
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[db], sc[r], o[db], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      dma_v(kt + 1);
+    }
+  }
+
+  // ---- merge the four waves' partials through LDS: wave w parks (O^T, m, l), then owns row group u = w of every d block
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const float l_w = l_run + __shfl_xor(l_run, 32);
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Kw[(db * 16 + r) * 64 + lane] = o[db][r];
+  Vw[lane] = m_run;
+  Vw[64 + lane] = l_w;
+  __syncthreads();
+  float mw[4], lw[4], m_all = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    mw[w] = Vs[w * BC * DK + lane];
+    lw[w] = Vs[w * BC * DK + 64 + lane];
+    m_all = fmaxf(m_all, mw[w]);
+  }
+  const float m_use = (m_all == -INFINITY) ? 0.f : m_all;
+  float l_all = 0.f, wgt[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    wgt[w] = __builtin_amdgcn_exp2f(mw[w] - m_use);
+    l_all += lw[w] * wgt[w];
+  }
+  const int u = wid;  // this wave's row group of the 32x32 C/D layout: registers r = 4u .. 4u+3 of every d block
+  float mo[NDB][4];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) a += Ks[w * BC * DK + (db * 16 + 4 * u + j) * 64 + lane] * wgt[w];
+      mo[db][j] = a;
+    }
+  // piece pj of row group u: rows j = pj*JP + e/NDB, block db = e%NDB (k_attention's store labelling)
+  auto pieces = [&](float scale, float* dst) {
+#pragma unroll
+    for (int pj = 0; pj < NDB; ++pj) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = mo[e % NDB][pj * JP + e / NDB] * scale;
+      *reinterpret_cast<f32x4*>(dst + 8 * NDB * u + 8 * pj) = v;
+    }
+  };
+  if (nsplit == 1) {
+    if (q < S) pieces(1.0f / l_all, out + ((size_t)b * S + q) * d + hd * DK + 4 * h);  // lens[b]==0 -> 0 * inf = NaN, as the reference
+    return;
+  }
+  // ---- several workgroups share this strip: publish the un-normalised partial, the last arriver merges in split order
+  const size_t Mrows = (size_t)gridDim.z * S;
+  const int H = gridDim.y;
+  if (q < S) {
+    const size_t row = (size_t)sp * Mrows + (size_t)b * S + q;
+    float* dst = opart + row * d + hd * DK + 4 * h + 8 * NDB * u;
+#pragma unroll
+    for (int pj = 0; pj < NDB; ++pj)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        __hip_atomic_store(dst + 8 * pj + e, mo[e % NDB][pj * JP + e / NDB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1
+    if (u == 0 && h == 0) {
+      __hip_atomic_store(mlpart + (row * H + hd) * 2, m_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mlpart + (row * H + hd) * 2 + 1, l_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* const last = reinterpret_cast<int*>(Vs);  // (the (m, l) words parked there were consumed before the barrier above)
+  if (tid == 0)
+    *last = __hip_atomic_fetch_add(tickets + ((size_t)b * H + hd) * nstrips + strip, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1;
+  __syncthreads();
+  if (!*last) return;
+  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  if (q >= S) return;
+  float mx = -INFINITY;
+  for (int s2 = 0; s2 < nsplit; ++s2) mx = fmaxf(mx, mlpart[((s2 * Mrows + (size_t)b * S + q) * H + hd) * 2]);
+  const float mx_use = (mx == -INFINITY) ? 0.f : mx;
+  f32x4 acc[NDB];
+#pragma unroll
+  for (int pj = 0; pj < NDB; ++pj) acc[pj] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float l = 0.f;
+  for (int s2 = 0; s2 < nsplit; ++s2) {
+    const size_t row = (size_t)s2 * Mrows + (size_t)b * S + q;
+    const float w2 = __builtin_amdgcn_exp2f(mlpart[(row * H + hd) * 2] - mx_use);
+    l += mlpart[(row * H + hd) * 2 + 1] * w2;
+    const float* src = opart + row * d + hd * DK + 4 * h + 8 * NDB * u;
+#pragma unroll
+    for (int pj = 0; pj < NDB; ++pj) acc[pj] += *reinterpret_cast<const f32x4*>(src + 8 * pj) * w2;
+  }
+  const float inv = 1.0f / l;
+  float* dst = out + ((size_t)b * S + q) * d + hd * DK + 4 * h + 8 * NDB * u;
+#pragma unroll
+  for (int pj = 0; pj < NDB; ++pj) *reinterpret_cast<f32x4*>(dst + 8 * pj) = acc[pj] * inv;
+#endif
+}
+
 // out[row, c] = sum_sp O_sp[row, c] 2^(m_sp - m) / sum_sp l_sp 2^(m_sp - m), m = max_sp m_sp (per row and head)
 __global__ __launch_bounds__(256) void k_attention_merge(const float* __restrict__ opart, const float* __restrict__ mlpart, int M,
                                                           int d, int H, int dk, int nsplit, float* __restrict__ out) {
@@ -316,25 +578,51 @@ __global__ __launch_bounds__(256) void k_attention_merge(const float* __restrict
 }
 
 hipError_t launch_attention(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, float* scratch,
-                            size_t scratch_floats, hipStream_t st) {
+                            size_t scratch_floats, int* tickets, hipStream_t st) {
   if (B <= 0 || S <= 0) return hipSuccess;
   const int d = H * dk;
   if ((long long)S * 3 * d * 4 >= (1ll << 31)) return hipErrorInvalidValue;  // 31-bit descriptor offsets per utterance
+  if (dk != 128 && dk != 64 && dk != 32) return hipErrorInvalidValue;
   const float c = 1.4426950408889634f / sqrtf((float)dk);
-  const int qtiles = (S + 127) / 128;
-  // Few workgroups (single-utterance latency): a workgroup's time is its serial sweep over the key tiles, 128 fp32
-  // MFMAs per tile and wave, so split the sweep over up to ATT_SPLIT_MAX workgroups per query tile until the launch
-  // has ~256 of them, then merge the partials.  Needs nsplit * (M*d + 2*M*H) floats of scratch.
-  int nsplit = 1;
+  const int qtiles = (S + 127) / 128, tiles = (S + 31) / 32;
   const long blocks = (long)qtiles * H * B;
   const size_t M = (size_t)B * S;
+  auto part_floats = [&](int n) { return (size_t)n * (M * d + 2 * M * H); };
+  if (blocks < ATT_SPLIT_MAX_BLOCKS) {
+    // Few workgroups (single-utterance latency, the encoder): a 128-query workgroup's time is its serial sweep over the
+    // key tiles.  First choice, k_attention_strip: a workgroup per 32-query strip whose four waves split the key axis, and up
+    // to nsplit such workgroups per strip merged by the last arriver — taken when that leaves every wave at most 4 key tiles
+    // (beyond that the shared K / V tiles of k_attention win: a strip's waves each pull their own).
+    const long strips = (long)tiles * H * B;
+    int nsplit = (int)((256 + strips - 1) / strips);
+    if (nsplit > (tiles + 3) / 4) nsplit = (tiles + 3) / 4;   // at least one key tile per wave
+    if (nsplit > ATT_SPLIT_MAX) nsplit = ATT_SPLIT_MAX;
+    if (nsplit > 1 && (!scratch || !tickets)) nsplit = 1;
+    while (nsplit > 1 && part_floats(nsplit) > scratch_floats) --nsplit;
+    int tpr = (tiles + 4 * nsplit - 1) / (4 * nsplit);
+    nsplit = ((tiles + tpr - 1) / tpr + 3) / 4;                // no workgroup of empty ranges
+    tpr = (tiles + 4 * nsplit - 1) / (4 * nsplit);
+    if (tpr <= 4) {
+      float* opart = nsplit > 1 ? scratch : nullptr;
+      float* mlpart = nsplit > 1 ? scratch + (size_t)nsplit * M * d : nullptr;
+      dim3 grid(tiles * nsplit, H, B), block(256);
+      if (dk == 128) hipLaunchKernelGGL((k_attention_strip<128>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, tickets);
+      else if (dk == 64) hipLaunchKernelGGL((k_attention_strip<64>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, tickets);
+      else hipLaunchKernelGGL((k_attention_strip<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, tickets);
+      return hipGetLastError();
+    }
+  }
+  // Otherwise k_attention; still few workgroups (long single utterances): split the key sweep over up to ATT_SPLIT_MAX
+  // workgroups per 128-query tile until the launch has ~256 of them, then merge the partials with k_attention_merge.
+  // Needs nsplit * (M*d + 2*M*H) floats of scratch.
+  int nsplit = 1;
   if (scratch && blocks < ATT_SPLIT_MAX_BLOCKS) {
     nsplit = (int)(256 / blocks);
     if (nsplit > ATT_SPLIT_MAX) nsplit = ATT_SPLIT_MAX;
-    if (nsplit > (S + 31) / 32) nsplit = (S + 31) / 32;  // at least one 32-key tile each
-    while (nsplit > 1 && (size_t)nsplit * (M * d + 2 * M * H) > scratch_floats) --nsplit;
+    if (nsplit > tiles) nsplit = tiles;  // at least one 32-key tile each
+    while (nsplit > 1 && part_floats(nsplit) > scratch_floats) --nsplit;
     if (nsplit < 1) nsplit = 1;
-    const int tiles = (S + 31) / 32, tps = (tiles + nsplit - 1) / nsplit;
+    const int tps = (tiles + nsplit - 1) / nsplit;
     nsplit = (tiles + tps - 1) / tps;  // no empty ranges: 25 tiles over 16 ranges are 13 ranges of two
   }
   float* opart = nsplit > 1 ? scratch : nullptr;
@@ -342,8 +630,7 @@ hipError_t launch_attention(const float* qkv, const long long* lens, int B, int 
   dim3 grid(qtiles * nsplit, H, B), block(256);
   if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart);
   else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart);
-  else if (dk == 32) hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart);
-  else return hipErrorInvalidValue;
+  else hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart);
   if (nsplit > 1)
     hipLaunchKernelGGL(k_attention_merge, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, opart, mlpart, (int)M, d, H, dk, nsplit, out);
   return hipGetLastError();

@@ -35,10 +35,6 @@ typedef __attribute__((address_space(3))) void* lds_ptr3_t;
 
 // x = hi + mid + lo with every piece exactly representable as bf16 (upper 16 bits of an fp32, lower 16 zero)
 __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
-#if defined(NS_LAB_B3_NOSPLIT)  // lab ablation: no VALU split (wrong numerics): what the kernel would cost with pre-split operands
-  hi = mid = lo = __float_as_uint(x);
-  return;
-#endif
   hi = __float_as_uint(x) & 0xffff0000u;
   const float r = x - __uint_as_float(hi);
   mid = __float_as_uint(r) & 0xffff0000u;

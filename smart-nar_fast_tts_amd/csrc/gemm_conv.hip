@@ -39,7 +39,15 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 [[maybe_unused]] constexpr int OOR = (int)0x80000000;  // voffset marker: beyond num_records -> the DMA writes zeros
 
-template <int BM, int BN, int BK, int KS, int WGM = 2, int WGN = 2, bool ROWEPI = false>
+// TICKET (small-grid launches whose N columns are one whole activation row, tiled BM x BN with BN < N): the row epilogue
+// of kernels.h RowEpilogue without a full-row tile and without a second launch.  Every workgroup stores its raw tile
+// (act(contraction + bias) + resid) write-through into p.Y, then draws a ticket on its row block's counter; the workgroup
+// that draws the last one (all ntn column tiles of the BM rows are then in memory) runs the row functions of rowln.h on
+// those rows — the same code, on the same values, as the separate k_layernorm / k_ln_linear_embed launch would: bit-identical.
+// Visibility across the 8 XCDs' private L2s / the CUs' L1s: sc1 (write-through) tile stores, every storing wave drains
+// vmcnt, barrier, ONE relaxed agent-scope fetch_add; the last arriver does ONE agent-scope acquire, then plain loads
+// (cdna_hip_programming.md Guideline 16, counter form).  The counters are zeroed by the first kernel of the forward phase.
+template <int BM, int BN, int BK, int KS, int WGM = 2, int WGN = 2, bool ROWEPI = false, bool TICKET = false>
 __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, int ntn) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type does not exist in the host pass; it only needs the stub
   constexpr int NW = WGM * WGN;       // waves per K-split group, arranged WGM x WGN over the block tile
@@ -55,6 +63,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
   static_assert(KS == 1 || ((KS * BN * BK) / (BM * BN) >= 1 && (KS - 1) <= 2 * ((KS * BN * BK) / (BM * BN))),
                 "split-K partial tiles must fit the B staging buffers");
   static_assert(!ROWEPI || (KS == 1 && BM <= 2 * BK && BN % 256 == 0 && BM % (WGM * WGN) == 0), "row epilogue: the BM x BN tile is parked in the two B staging buffers");
+  static_assert(!(ROWEPI && TICKET), "a full-row tile needs no ticket");
 
   // Four DISTINCT LDS objects (not [2][...] arrays) and a 2x unrolled K loop with a static buffer index: hipcc tracks
   // in-flight LDS-DMA per LDS object, so a ds_read from As0 does not wait for a DMA that is filling As1.  With one
@@ -226,16 +235,18 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
           for (int r = 0; r < 16; ++r) red[(((wid * TM + mi) * TN + ni) * 16 + r) * 64 + lane] = acc[mi][ni][r];
     }
     __syncthreads();
-    if (grp > 0) return;
+    if (!TICKET && grp > 0) return;  // (ticketed: the other groups' waves stay for the row phase below)
+    if (grp == 0) {
 #pragma unroll
-    for (int g2 = 1; g2 < KS; ++g2) {
-      const float* red = ((g2 - 1) / PER_OBJ ? Bs1 : Bs0) + ((g2 - 1) % PER_OBJ) * TILE;
+      for (int g2 = 1; g2 < KS; ++g2) {
+        const float* red = ((g2 - 1) / PER_OBJ ? Bs1 : Bs0) + ((g2 - 1) % PER_OBJ) * TILE;
 #pragma unroll
-      for (int mi = 0; mi < TM; ++mi)
+        for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
+          for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mi][ni][r] += red[(((wid * TM + mi) * TN + ni) * 16 + r) * 64 + lane];
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] += red[(((wid * TM + mi) * TN + ni) * 16 + r) * 64 + lane];
+      }
     }
   }
 
@@ -300,6 +311,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
       }
     }
   } else {
+    if (!TICKET || grp == 0) {
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
       const int n = n0 + wn0 + ni * 32 + ecol;
@@ -323,18 +335,52 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
           if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
           else if (p.act == ACT_TANH) v = tanhf(v);
           if (p.resid) v += rs[r];
-          p.Y[(size_t)m * p.ldy + n] = v;
+          if constexpr (TICKET) __hip_atomic_store(p.Y + (size_t)m * p.ldy + n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1
+          else p.Y[(size_t)m * p.ldy + n] = v;
         }
+      }
+    }
+    }
+    if constexpr (TICKET) {
+      constexpr int NWALL = NW * KS;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its write-through stores have left
+      __syncthreads();
+      int* const last = reinterpret_cast<int*>(As0);      // the staging LDS is idle; no extra LDS object (see above)
+      if (tid == 0) *last = __hip_atomic_fetch_add(p.e.ticket + tile_m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ntn - 1;
+      __syncthreads();
+      if (!*last) return;
+      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __syncthreads();
+      constexpr int NV = 4;  // row widths up to 1024 (ln_moments / ln_store skip float4s past N)
+      for (int ml = wall; ml < BM; ml += NWALL) {
+        const int m = m0 + ml;
+        if (m >= p.M) break;
+        const int b = m / p.S, t = m - b * p.S;
+        const bool masked = p.e.lens && (long long)t >= p.e.lens[b];
+        if (p.epi == EPI_LN && masked) {
+          for (int c = lane * 4; c < p.N; c += 256) *reinterpret_cast<f32x4*>(p.e.y_out + (size_t)m * p.N + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+          continue;
+        }
+        f32x4 v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int c = lane * 4 + i * 256;
+          v[i] = c < p.N ? *reinterpret_cast<const f32x4*>(p.Y + (size_t)m * p.ldy + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float mean, rstd;
+        ln_moments<NV>(v, p.N, lane, mean, rstd);
+        if (p.epi == EPI_LN) ln_store<NV>(v, p.N, lane, mean, rstd, p.e.ln_g, p.e.ln_b, p.e.y_out + (size_t)m * p.N);
+        else predictor_row_tail<NV>(v, p.N, lane, mean, rstd, p.e, m, t, masked);
       }
     }
   }
 #endif
 }
 
-template <int BM, int BN, int BK, int KS = 1, int WGM = 2, int WGN = 2, bool ROWEPI = false>
+template <int BM, int BN, int BK, int KS = 1, int WGM = 2, int WGN = 2, bool ROWEPI = false, bool TICKET = false>
 static hipError_t launch_t(const ConvGemm& p, hipStream_t st) {
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN, ROWEPI>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, p, ntn);
+  hipLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN, ROWEPI, TICKET>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, p, ntn);
   return hipGetLastError();
 }
 
@@ -347,14 +393,21 @@ hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) {
   if (p.Cin % 16 != 0 || (p.ldx & 3) != 0) return hipErrorInvalidValue;
   // descriptor offsets are 31-bit: a tile's rows (BM + KW) * ldx and BN * K floats must stay below 2^29 floats
   if ((long long)(256 + p.KW) * p.ldx >= (1ll << 29) || (long long)512 * p.KW * p.Cin >= (1ll << 29)) return hipErrorInvalidValue;
+  if (p.epi != EPI_NONE && p.e.ticket) {
+    // ticketed row epilogue on the small-grid ladder (same tile choices as below): the smallest tile that still gives about
+    // one workgroup per CU, the rest of the CU spent on an in-workgroup K split
+    if (p.Cin % 32 || p.N % 4 || p.N > 1024 || p.ldy != p.N || (p.resid && (p.ldr & 3)) || (p.epi == EPI_LN && !p.e.y_out)) return hipErrorInvalidValue;
+    const long rows32 = (p.M + 31) / 32;
+    auto wgs = [&](long rows, int bn) { return rows * ((p.N + bn - 1) / bn); };
+    const int nch = p.KW * (p.Cin / 32);
+    if (wgs(rows32, 32) <= 256) return nch >= 16 ? launch_t<32, 32, 32, 8, 1, 1, false, true>(p, st) : launch_t<32, 32, 32, 4, 1, 1, false, true>(p, st);
+    if (wgs(rows32, 64) <= 256) return launch_t<32, 64, 32, 4, 1, 2, false, true>(p, st);
+    if (wgs(rows32, 128) <= 512) return launch_t<32, 128, 32, 2, 1, 4, false, true>(p, st);
+    return launch_t<64, 64, 32, 1, 2, 2, false, true>(p, st);
+  }
   if (p.epi != EPI_NONE) {
     // full-row tile: 32 rows x N columns, N / 32 waves side by side with one 32x32 MFMA tile each
     if (!conv_gemm_row_epilogue_ok(p.M, p.N, p.Cin) || (p.ldy & 3) || (p.resid && (p.ldr & 3))) return hipErrorInvalidValue;
-#if defined(NS_LAB_ROW64)
-    if (p.N == 256) return launch_t<64, 256, 32, 1, 2, 4, true>(p, st);
-#elif defined(NS_LAB_ROW64W16)
-    if (p.N == 256) return launch_t<64, 256, 32, 1, 2, 8, true>(p, st);
-#endif
     if (p.N == 256) return launch_t<32, 256, 32, 1, 1, 8, true>(p, st);
     return launch_t<32, 512, 32, 1, 1, 16, true>(p, st);
   }

@@ -22,7 +22,12 @@ struct RowEpilogue {
   const long long* lens;
   const float* wlin; const float* blin; float* pred; float control; const float* target;
   const float* bins; int n_edges; const float* emb; const float* x_in; const float* pos; float* x_out; int D;
+  // ticketed form (small grids, gemm_conv.hip TICKET): the GEMM tiles N with BN < N, stores the raw rows into ConvGemm::Y
+  // ([M, N], ldy == N) and the LAST workgroup to finish a row block applies the row epilogue, EPI_LN writing y_out [M, N].
+  // ticket: conv_gemm_ticket_ints(M) zeroed ints, used by this launch only; nullptr selects the full-row tile.
+  float* y_out; int* ticket;
 };
+inline int conv_gemm_ticket_ints(int M) { return (M + 31) / 32; }
 
 // Y[m, n] = act( sum_{j<KW} sum_{c<Cin} X[m + j - pad, c] * W[n][j*Cin + c] + bias[n] ) + resid[m, n]
 // rows of X outside the utterance's [0, S) window read as zero ("same" zero padding of nn.Conv1d).
@@ -55,8 +60,10 @@ bool conv_gemm_row_epilogue_ok(int M, int N, int Cin);
 // (16, not 8: a single 788-frame utterance has 14 (query tile, head) pairs x 25 key tiles; 13 two-tile ranges instead of 8
 //  four-tile ranges take the decoder attention from 24.5 to ~19 us, single-utterance p50 1.08 -> 1.06 ms, same box)
 constexpr int ATT_SPLIT_MAX = 16, ATT_SPLIT_MAX_BLOCKS = 128;
+// tickets (nullable): attention_ticket_ints(B, S, H) ZEROED ints for the strip kernel's last-arriver merge (small grids)
+inline int attention_ticket_ints(int B, int S, int H) { return B * H * ((S + 31) / 32); }
 hipError_t launch_attention(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, float* scratch,
-                            size_t scratch_floats, hipStream_t st);
+                            size_t scratch_floats, int* tickets, hipStream_t st);
 
 // ---- row kernels (rowops.hip) -----------------------------------------------------------------
 // y = LayerNorm_C(x) * g + b ; rows with t >= lens[b] are written as zero when lens != nullptr
@@ -70,8 +77,10 @@ hipError_t launch_ln_linear_embed(const float* x, const float* g, const float* b
                                   float* x_out, int D, hipStream_t st);
 // out[m,:] = emb[texts[m],:] + pos[t,:]
 // token ids outside [0, n_vocab) read row 0 (and are reported by launch_duration_tail)
+// zero / nzero (nullable): ticket counters of the forward phase this kernel opens, zeroed by it (rowops.hip zero_words);
+// the same pair on launch_length_regulate / launch_gaussian_upsampling
 hipError_t launch_embed_pos(const long long* texts, const float* emb, const float* pos, float* out, int M, int S, int D, int n_vocab,
-                            hipStream_t st);
+                            int* zero, int nzero, hipStream_t st);
 hipError_t launch_add_pos(const float* x, const float* pos, float* out, int M, int S, int D, hipStream_t st);
 hipError_t launch_bucketize(const float* v, int n, const float* bins, int n_edges, long long* idx, hipStream_t st);
 hipError_t launch_mask_from_lengths(const long long* lens, int B, int max_len, uint8_t* mask, hipStream_t st);
@@ -79,14 +88,16 @@ hipError_t launch_sinusoid(int n_pos, int d, float* out, hipStream_t st);
 hipError_t launch_duration_round(const float* log_d, int n, float d_control, float* d_rounded, hipStream_t st);
 hipError_t launch_duration_scan(const float* d_rounded, int B, int L, int32_t* cum, long long* mel_lens, hipStream_t st);
 // mel_mask (nullable): also writes get_mask_from_lengths(mel_len) for the [B,T] frame grid
+// status (nullable, [B] int32): per-utterance NS_STATUS_* bits of ns_forward_mel (needs mel_lens for the bad-token bit)
 hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int L, int D, int T, float* out, uint8_t* mel_mask,
-                                  hipStream_t st);
+                                  const long long* mel_lens, int32_t* status, int* zero, int nzero, hipStream_t st);
 // phase-1 tail in one launch: src mask, duration_round (two copies), duration_scan; mel_lens[b] = -1 when utterance b
 // holds a token id outside [0, n_vocab) (texts may be nullptr: no check)
 hipError_t launch_duration_tail(const float* log_d, const long long* src_lens, const long long* texts, int n_vocab, int B, int L,
                                 float d_control, float* d_rounded, float* d_keep, int32_t* cum, long long* mel_lens, uint8_t* src_mask,
                                 long long* mel_lens_host /* nullable: device-visible host copy */, hipStream_t st);
 hipError_t launch_gaussian_upsampling(const float* x, const float* dur, int B, int L, int D, int T, int T_out,
-                                      float* out, float* s, float* w, const long long* own_len, hipStream_t st);
+                                      float* out, float* s, float* w, const long long* own_len, int32_t* status, int* zero, int nzero,
+                                      hipStream_t st);
 
 }  // namespace ns

@@ -14,6 +14,12 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
 constexpr float LN_EPS = 1e-5f;  // torch.nn.LayerNorm default
 
 // torch.bucketize(v, bins, right=False) (model/modules.py:86-88,97-99), wave-cooperative: the index is the number
@@ -73,10 +79,32 @@ __device__ __forceinline__ void ln_store(const f32x4 (&v)[NV], int C, int lane, 
 // VarianceAdaptor.forward (model/modules.py:80-100,139-149):
 //   idx = bucketize(pred*control, bins)  (right=False; NaN -> n_bins-1)
 //   x_out[m,:] = x_in[m,:] + emb[idx,:]  (+ pos[t,:]: MelDecoder's position add, transformer/Models.py:222,231)
+// The row feeds a DISCONTINUOUS consumer (duration rounding, torch.bucketize): layer_norm_2 and the Linear(F->1) dot are
+// therefore evaluated in float64 from the fp32 row (mean, centred variance, normalisation, dot: ~1k flops per row, free next
+// to the convolution that produced it), so that this tail adds no rounding of its own to the distance from the reference's
+// value — what remains is the fp32 summation order of the contractions upstream (profiles/r03_bucket_edge_deviation.md).
+// `mean` / `rstd` (the fp32 moments of the shared LayerNorm path) are not used here.
 template <int NV>
-__device__ __forceinline__ void predictor_row_tail(const f32x4 (&v)[NV], int C, int lane, float mean, float rstd, const RowEpilogue& e,
+__device__ __forceinline__ void predictor_row_tail(const f32x4 (&v)[NV], int C, int lane, float /*mean*/, float /*rstd*/, const RowEpilogue& e,
                                                    int m, int t, bool masked) {
-  float dot = 0.f;
+  double s1 = 0.0;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s1 += ((double)v[i][0] + (double)v[i][1]) + ((double)v[i][2] + (double)v[i][3]);
+  const double mu = wave_sum(s1) / (double)C;
+  double s2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < C) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double dl = (double)v[i][k] - mu;
+        s2 += dl * dl;
+      }
+    }
+  }
+  const double rs = 1.0 / sqrt(wave_sum(s2) / (double)C + (double)LN_EPS);
+  double dot = 0.0;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + i * 256;
@@ -85,10 +113,10 @@ __device__ __forceinline__ void predictor_row_tail(const f32x4 (&v)[NV], int C, 
       const f32x4 bb = *reinterpret_cast<const f32x4*>(e.ln_b + c);
       const f32x4 ww = *reinterpret_cast<const f32x4*>(e.wlin + c);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) dot += ((v[i][k] - mean) * rstd * gg[k] + bb[k]) * ww[k];
+      for (int k = 0; k < 4; ++k) dot += (((double)v[i][k] - mu) * rs * (double)gg[k] + (double)bb[k]) * (double)ww[k];
     }
   }
-  float pv = wave_sum(dot) + e.blin[0];
+  float pv = (float)(wave_sum(dot) + (double)e.blin[0]);
   if (masked) pv = 0.f;
   // model/modules.py:82-89: with a target the embedding comes from bucketize(target) and the prediction is returned
   // unscaled; without one prediction = prediction * control and the embedding comes from the scaled prediction

@@ -4,6 +4,15 @@
 
 namespace ns {
 
+// The first kernel of a forward phase also zeroes that phase's ticket counters (gemm_conv.hip TICKET, attention.hip): the
+// launches that draw tickets come later on the same stream, so the kernel boundary orders the zeroes before them, and no
+// memset node / extra launch is needed.
+__device__ __forceinline__ void zero_words(int* __restrict__ z, int n) {
+  if (!z) return;
+  const int nthr = gridDim.x * gridDim.y * blockDim.x;
+  for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += nthr) z[i] = 0;
+}
+
 // Loads row `x` (C floats, C % 4 == 0, C <= 1024) as up to NV float4 per lane and returns mean / rstd.
 template <int NV>
 __device__ __forceinline__ void ln_stats(const float* x, int C, int lane, f32x4 (&v)[NV], float& mean, float& rstd) {
@@ -108,7 +117,8 @@ hipError_t launch_bucketize(const float* v, int n, const float* bins, int n_edge
 // A token id outside [0, n_vocab) (nn.Embedding raises IndexError) reads row 0 here and is reported by the duration tail.
 __global__ __launch_bounds__(256) void k_embed_pos(const long long* __restrict__ texts, const float* __restrict__ emb,
                                                     const float* __restrict__ pos, float* __restrict__ out, int M, int S, int D,
-                                                    int n_vocab) {
+                                                    int n_vocab, int* __restrict__ zero, int nzero) {
+  zero_words(zero, nzero);
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
@@ -122,9 +132,9 @@ __global__ __launch_bounds__(256) void k_embed_pos(const long long* __restrict__
   }
 }
 hipError_t launch_embed_pos(const long long* texts, const float* emb, const float* pos, float* out, int M, int S, int D, int n_vocab,
-                            hipStream_t st) {
+                            int* zero, int nzero, hipStream_t st) {
   if (M <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_embed_pos, dim3((M + 3) / 4), dim3(256), 0, st, texts, emb, pos, out, M, S, D, n_vocab);
+  hipLaunchKernelGGL(k_embed_pos, dim3((M + 3) / 4), dim3(256), 0, st, texts, emb, pos, out, M, S, D, n_vocab, zero, nzero);
   return hipGetLastError();
 }
 
@@ -274,11 +284,19 @@ hipError_t launch_duration_tail(const float* log_d, const long long* src_lens, c
   return hipGetLastError();
 }
 
+// ns_forward_mel's per-utterance status word (include/nar_fs2.h NS_STATUS_*): bit 0 = the utterance is longer than the T the
+// caller chose (its frames past T are cut off), bit 1 = phase 1 flagged a token id outside the vocabulary (mel_lens[b] = -1)
+__device__ __forceinline__ int32_t forward_status(long long total, int T, long long mel_len) {
+  return (total > (long long)T ? 1 : 0) | (mel_len < 0 ? 2 : 0);
+}
+
 // LengthRegulator.LR + pad (model/modules.py:201-218, utils/tools.py:288-306) as a gather: output frame t of
 // utterance b copies encoder row i = first index with cum[b][i] > t; frames at t >= mel_len[b] are zero.
 __global__ __launch_bounds__(256) void k_length_regulate(const float* __restrict__ x, const int32_t* __restrict__ cum, int L,
                                                           int D, int T, int M, float* __restrict__ out,
-                                                          uint8_t* __restrict__ mel_mask) {
+                                                          uint8_t* __restrict__ mel_mask, const long long* __restrict__ mel_lens,
+                                                          int32_t* __restrict__ status, int* __restrict__ zero, int nzero) {
+  zero_words(zero, nzero);
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
@@ -286,6 +304,8 @@ __global__ __launch_bounds__(256) void k_length_regulate(const float* __restrict
   const int32_t* cb = cum + (size_t)b * L;
   const int total = L > 0 ? cb[L - 1] : 0;
   if (mel_mask && lane == 0) mel_mask[m] = t >= total ? 1 : 0;  // get_mask_from_lengths(mel_len): total IS mel_len[b]
+  // one writer per utterance: what a caller that chose T without reading mel_lens (capacity mode) must be able to find out later
+  if (status && t == 0 && lane == 0) status[b] = forward_status(total, T, mel_lens ? mel_lens[b] : 0ll);
   float* dst = out + (size_t)m * D;
   if (t >= total) {
     for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<f32x4*>(dst + c) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -300,12 +320,21 @@ __global__ __launch_bounds__(256) void k_length_regulate(const float* __restrict
   const float* src = x + ((size_t)b * L + lo) * D;
   for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(src + c);
 }
+// T == 0 (nothing to regulate): only the status words
+__global__ void k_status_only(const int32_t* __restrict__ cum, int L, int B, const long long* __restrict__ mel_lens,
+                              int32_t* __restrict__ status) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) status[b] = forward_status(L > 0 ? cum[(size_t)b * L + L - 1] : 0, 0, mel_lens ? mel_lens[b] : 0ll);
+}
 hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int L, int D, int T, float* out, uint8_t* mel_mask,
-                                  hipStream_t st) {
+                                  const long long* mel_lens, int32_t* status, int* zero, int nzero, hipStream_t st) {
   const int M = B * T;
-  if (M <= 0) return hipSuccess;
+  if (M <= 0) {
+    if (B > 0 && status) hipLaunchKernelGGL(k_status_only, dim3((B + 63) / 64), dim3(64), 0, st, cum, L, B, mel_lens, status);
+    return hipGetLastError();
+  }
   if (D % 4 != 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_length_regulate, dim3((M + 3) / 4), dim3(256), 0, st, x, cum, L, D, T, M, out, mel_mask);
+  hipLaunchKernelGGL(k_length_regulate, dim3((M + 3) / 4), dim3(256), 0, st, x, cum, L, D, T, M, out, mel_mask, mel_lens, status, zero, nzero);
   return hipGetLastError();
 }
 
@@ -314,10 +343,13 @@ hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int
 // t spans [0, T) with T = max_b sum(d): rows past an utterance's own length are NOT zeroed; rows in
 // [T, T_out) are the zero padding of pad(output, max_len).
 __global__ __launch_bounds__(256) void k_gauss_centers(const float* __restrict__ dur, int L, float* __restrict__ centers,
-                                                        float* __restrict__ s) {
+                                                        float* __restrict__ s, const long long* __restrict__ own_len, int T,
+                                                        int32_t* __restrict__ status, int* __restrict__ zero, int nzero) {
+  zero_words(zero, nzero);
   // sequential fp32 cumsum per utterance, as torch.cumsum on CPU accumulates
   const int b = blockIdx.x;
   if (threadIdx.x != 0) return;
+  if (status) status[b] = own_len ? forward_status(own_len[b], T, own_len[b]) : 0;
   float e = 0.f;
   for (int l = 0; l < L; ++l) {
     const float dl = dur[(size_t)b * L + l];
@@ -412,11 +444,12 @@ __global__ __launch_bounds__(256) void k_gauss_upsample(const float* __restrict_
 #endif
 }
 hipError_t launch_gaussian_upsampling(const float* x, const float* dur, int B, int L, int D, int T, int T_out, float* out,
-                                      float* s, float* w, const long long* own_len, hipStream_t st) {
+                                      float* s, float* w, const long long* own_len, int32_t* status, int* zero, int nzero,
+                                      hipStream_t st) {
   if (B <= 0 || T_out <= 0) return hipSuccess;
   // s holds B sums followed by B*L Gaussian centres (scratch)
   float* centers = s + B;
-  hipLaunchKernelGGL(k_gauss_centers, dim3(B), dim3(64), 0, st, dur, L, centers, s);
+  hipLaunchKernelGGL(k_gauss_centers, dim3(B), dim3(64), 0, st, dur, L, centers, s, own_len, T, status, zero, nzero);
   hipLaunchKernelGGL(k_gauss_upsample, dim3((T_out + 31) / 32, B), dim3(256), 0, st, x, centers, L, D, T, T_out, out, w, own_len);
   return hipGetLastError();
 }

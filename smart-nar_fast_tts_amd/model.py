@@ -11,6 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
+import time
 from collections import OrderedDict
 
 import numpy as np
@@ -126,28 +127,62 @@ class FastSpeech2Align:
         return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in self._sd.items())
 
     def _stage(self, key: str, a: np.ndarray):
-        """Hand one entry to the native staging area; it validates the key name and the shape (raises on mismatch)."""
+        """Hand one (already validated) entry to the native staging area."""
         shape = (C.c_int64 * a.ndim)(*a.shape)
         _lib.check(self._lib.ns_set_weight(self._h, key.encode(), C.c_void_p(a.ctypes.data), shape, a.ndim),
                    "load_state_dict")
 
+    def _check(self, key: str, a: np.ndarray) -> str:
+        """'' when the native side accepts this key name and shape, else its error text.  No side effect on the model."""
+        shape = (C.c_int64 * a.ndim)(*a.shape)
+        if self._lib.ns_check_weight(self._h, key.encode(), shape, a.ndim) == 0:
+            return ""
+        return self._lib.ns_last_error().decode()
+
     def load_state_dict(self, state_dict, strict: bool = True):
         """Accepts the reference's checkpoint["model"] (utils/model.py:21-22).  ``mel_encoder.*`` (training-only
-        aligner) and ``num_batches_tracked`` entries are accepted and ignored.  An unexpected key or a shape mismatch
-        raises and leaves the previously loaded weights untouched."""
+        aligner) and ``num_batches_tracked`` entries are accepted and ignored.  Like ``nn.Module.load_state_dict``:
+        a shape mismatch always raises; an unexpected key raises when ``strict`` and is skipped (and returned)
+        otherwise; missing keys are only possible on the first load and raise when ``strict``.  Every entry is validated
+        BEFORE anything is handed to the native side, so a rejected state dict leaves the loaded weights in use."""
         new = OrderedDict()
         if self._stats is not None and not self._loaded:
             pb, eb = wl.variance_bins(self.model_config, self._stats)
             new["variance_adaptor.pitch_bins"] = pb
             new["variance_adaptor.energy_bins"] = eb
+        unexpected, errors = [], []
         for k, v in state_dict.items():
             if k.startswith("mel_encoder.") or k.endswith("num_batches_tracked"):
                 continue
             a = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
-            new[k] = np.ascontiguousarray(a, dtype=np.float32)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            err = self._check(k, a)
+            if err and "unexpected key" in err:
+                unexpected.append(k)
+                continue
+            if err:
+                errors.append(err)
+                continue
+            new[k] = a
+        if strict and unexpected:
+            errors.append("unexpected key(s): " + ", ".join(repr(k) for k in unexpected))
+        if errors:
+            raise RuntimeError("load_state_dict: " + "; ".join(errors))
         merged = OrderedDict(self._sd)
         merged.update(new)
-        for k, a in merged.items():  # validated by the native side BEFORE anything is kept
+        missing = []
+        if not self._loaded:  # a partial FIRST load: say which keys are absent before touching native state
+            missing = [k for k in wl.inference_keys(self.model_config) if k not in merged]
+            if missing and strict:
+                raise RuntimeError("load_state_dict: missing key(s): " + ", ".join(missing))
+            if missing:  # strict=False: an nn.Module keeps its constructor's initialisation for keys that did not arrive
+                if self._stats is None:
+                    raise RuntimeError("load_state_dict(strict=False) with missing keys needs <preprocessed_path>/stats.json "
+                                       "for the constructor-equivalent initialisation of the rest: " + ", ".join(missing))
+                init = wl.default_init_state_dict(self.model_config, self._stats)
+                for k in missing:
+                    merged[k] = init[k]
+        for k, a in merged.items():
             self._stage(k, a)
         self._sd = merged
         self._loaded, self._adopted = True, False
@@ -155,7 +190,7 @@ class FastSpeech2Align:
             self._device = torch.device("cuda", torch.cuda.current_device())
         if self._device is not None:
             self._upload(staged=True)
-        return [], []
+        return missing, unexpected
 
     def _bind_arena(self):
         nbytes = self._lib.ns_arena_bytes(self._h)
@@ -247,15 +282,55 @@ class FastSpeech2Align:
     def __call__(self, *args, **kwargs):
         return self.forward(*args, **kwargs)
 
+    SPIN_US = float(os.environ.get("NS_SPIN_US", "300"))  # busy-wait budget for the mid-forward hand-over, then block
+
+    def _wait_phase1(self, dev):
+        """Wait for phase 1 on the launch stream.  A blocking synchronize sleeps and costs ~50 us of wake-up latency per
+        forward (single-utterance p50 1.12 vs 1.07 ms), so spin on an event first — but only for SPIN_US microseconds
+        (phase 1 of one utterance takes ~0.35 ms): a large batch, or many ranks / server threads sharing the host, must not
+        burn a core and hold the GIL for milliseconds.  After the budget the thread blocks in event.synchronize()."""
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        if self.SPIN_US > 0:
+            deadline = time.perf_counter() + self.SPIN_US * 1e-6
+            while not done.query():
+                if time.perf_counter() > deadline:
+                    done.synchronize()
+                    break
+        else:
+            done.synchronize()
+
+    def check_status(self):
+        """Raise what the synchronous path raises on the spot, for the most recent forward issued in capacity mode
+        (``max_mel_len=<int>``): IndexError for a token id outside the vocabulary (nn.Embedding, transformer/Models.py:89),
+        ValueError when an utterance turned out longer than ``max_mel_len`` (its frames past it were cut off).
+        Synchronises with that forward; returns the [B] status words (include/nar_fs2.h NS_STATUS_*) as a list."""
+        st = getattr(self, "last_status", None)
+        if st is None:
+            return []
+        words = st.cpu().tolist()
+        bad = [i for i, w in enumerate(words) if w & _lib.STATUS_BAD_TOKEN]
+        if bad:
+            raise IndexError(f"index out of range in self: token id outside [0, {self._cfg.n_vocab}) in utterance(s) {bad}")
+        cut = [i for i, w in enumerate(words) if w & _lib.STATUS_TRUNCATED]
+        if cut:
+            raise ValueError(f"max_mel_len is smaller than the longest utterance: utterance(s) {cut} were cut off")
+        return words
+
     def forward(self, speakers, texts, src_lens, max_src_len, mels=None, mel_lens=None, max_mel_len=None,
                 p_targets=None, e_targets=None, p_control=1.0, e_control=1.0):
         """model/fastspeech2_align.py:30-100, inference branch.  ``speakers`` is accepted and ignored
         (no speaker embedding exists in the reference; multi_speaker is False).
 
-        Extension for multi-GPU global-pad mode: ``max_mel_len`` may be an int >= max(mel_lens)
-        or a callable ``f(local_max_tensor) -> int`` (e.g. ``sharding.global_max``); the mel axis is then padded
-        (and masked) to that length.  The reference itself cannot run with max_mel_len set at inference
-        (its mask is built from max(mel_len), model/modules.py:136-137)."""
+        Extensions on ``max_mel_len`` (the reference itself cannot run with it set at inference: its mask is built from
+        max(mel_len), model/modules.py:136-137; the `max_len` semantics followed are model/modules.py:128-131,204-213):
+
+        * an ``int``: CAPACITY MODE.  The mel axis is padded and masked to that length and the whole forward is enqueued
+          without a host synchronisation (nothing waits for ``mel_lens``).  An utterance longer than the capacity is cut off
+          and a bad token id cannot raise on the spot; both are recorded per utterance on the device and raised by
+          ``check_status()``.
+        * a callable ``f(local_max_tensor) -> int`` (e.g. ``sharding.global_max``, multi-GPU global-pad mode):
+          synchronous like the default path, padded to the returned length."""
         if mel_lens is not None:
             raise NotImplementedError(
                 "teacher-forced / training branch is out of scope; in the reference it calls an undefined "
@@ -300,28 +375,31 @@ class FastSpeech2Align:
                 _lib.ptr(None if e_frame else target("e_targets", e_targets, (B, L))),
                 _lib.ptr(ws_enc), ws_enc.numel(), _lib.ptr(log_d), _lib.ptr(d_rounded), _lib.ptr(src_masks),
                 _lib.ptr(out_mel_lens), _lib.ptr(p_pred), _lib.ptr(e_pred), _lib.ptr(pin), st), "ns_forward_durations")
-            # the one device->host read: output shapes depend on max(mel_len)
-            # (the reference syncs here too: utils/tools.py:92, plus B*L .item() calls at model/modules.py:222)
-            # (a token id outside [0, n_vocab) comes back as mel_len = -1 for its utterance; nn.Embedding raises IndexError)
-            # (the kernel that produces mel_lens also wrote them into pinned host memory: a stream sync, no D2H copy)
-            # Busy-wait on an event instead of stream.synchronize(): the blocking wait sleeps and costs ~50 us of wake-up
-            # latency per forward (measured: single-utterance p50 1.12 vs 1.07 ms), the query loop returns within a microsecond
-            done = torch.cuda.Event()
-            done.record(torch.cuda.current_stream(dev))
-            while not done.query():
-                pass
-            ml_host = pin.clone()
-            if int(ml_host.min()) < 0:
-                bad = [i for i, v in enumerate(ml_host.tolist()) if v < 0]
-                raise IndexError(f"index out of range in self: token id outside [0, {self._cfg.n_vocab}) in utterance(s) {bad}")
-            if callable(max_mel_len):
-                T = int(max_mel_len(ml_host.max().to(dev)))
+            status = torch.empty(B, dtype=torch.int32, device=dev)
+            self.last_status = status
+            if isinstance(max_mel_len, (int, np.integer)) and not isinstance(max_mel_len, bool):
+                # CAPACITY MODE (model/modules.py:128-131,204-213 `max_len` semantics): the caller fixes the mel axis, so phase 2
+                # is enqueued right behind phase 1 — no event wait, no host read.  What the synchronous path checks on the host
+                # (token ids in range, T >= the longest utterance) lands in `status` on the device: check_status() raises later.
+                T = int(max_mel_len)
+                if T < 0:
+                    raise ValueError(f"max_mel_len ({T}) is negative")
             else:
-                T = int(ml_host.max())
-                if max_mel_len is not None:
-                    if int(max_mel_len) < T:
-                        raise ValueError(f"max_mel_len ({int(max_mel_len)}) is smaller than the longest utterance ({T})")
-                    T = int(max_mel_len)
+                # the one device->host read: output shapes depend on max(mel_len)
+                # (the reference syncs here too: utils/tools.py:92, plus B*L .item() calls at model/modules.py:222)
+                # (a token id outside [0, n_vocab) comes back as mel_len = -1 for its utterance; nn.Embedding raises IndexError)
+                # (the kernel that produces mel_lens also wrote them into pinned host memory: a stream sync, no D2H copy)
+                self._wait_phase1(dev)
+                ml_host = pin.clone()
+                if int(ml_host.min()) < 0:
+                    bad = [i for i, v in enumerate(ml_host.tolist()) if v < 0]
+                    raise IndexError(f"index out of range in self: token id outside [0, {self._cfg.n_vocab}) in utterance(s) {bad}")
+                if callable(max_mel_len):
+                    T = int(max_mel_len(ml_host.max().to(dev)))
+                    if T < int(ml_host.max()):
+                        raise ValueError(f"max_mel_len() returned {T}, smaller than the longest utterance ({int(ml_host.max())})")
+                else:
+                    T = int(ml_host.max())
             n_mel = self._cfg.n_mel
             mel = torch.empty(B, T, n_mel, **f32)
             post = torch.empty(B, T, n_mel, **f32)
@@ -334,12 +412,12 @@ class FastSpeech2Align:
             # (model/fastspeech2_align.py:70-78): the embedding then comes from bucketize(target)
             tg = [target("p_targets", p_targets, (B, T)) if p_frame else None,
                   target("e_targets", e_targets, (B, T)) if e_frame else None]
-            if T > 0:
-                ws_dec_bytes = lib.ns_decoder_ws_bytes(self._h, B, L, T)
-                ws_dec = self._workspace("dec", ws_dec_bytes)
-                _lib.check(lib.ns_forward_mel(self._h, B, L, T, _lib.ptr(out_mel_lens), float(p_control), float(e_control),
-                                              _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(ws_enc), _lib.ptr(ws_dec), ws_dec.numel(), _lib.ptr(mel),
-                                              _lib.ptr(post), _lib.ptr(p_pred if p_frame else None),
-                                              _lib.ptr(e_pred if e_frame else None), _lib.ptr(mel_masks), st),
-                           "ns_forward_mel")
+            # (T == 0 is still a call: the native side then only fills `status`)
+            ws_dec_bytes = lib.ns_decoder_ws_bytes(self._h, B, L, max(T, 1))
+            ws_dec = self._workspace("dec", ws_dec_bytes)
+            _lib.check(lib.ns_forward_mel(self._h, B, L, T, _lib.ptr(out_mel_lens), float(p_control), float(e_control),
+                                          _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(ws_enc), _lib.ptr(ws_dec), ws_dec.numel(), _lib.ptr(mel),
+                                          _lib.ptr(post), _lib.ptr(p_pred if p_frame else None),
+                                          _lib.ptr(e_pred if e_frame else None), _lib.ptr(mel_masks), _lib.ptr(status), st),
+                       "ns_forward_mel")
         return (mel, post, p_pred, e_pred, log_d, d_rounded, src_masks, mel_masks, src_lens, out_mel_lens, None, None)

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import copy
 import math
+import re
 from collections import OrderedDict
 
 import numpy as np
@@ -226,6 +227,58 @@ def synth_state_dict(model_cfg: dict, seed: int = 0, frames_per_phoneme: float =
     return sd
 
 
+def inference_shapes(model_cfg: dict) -> "OrderedDict[str, tuple]":
+    """Name -> shape of every state-dict entry the inference forward REQUIRES (reference key names).
+    ``position_enc`` tables (deterministic, regenerated when absent), ``num_batches_tracked`` and ``mel_encoder.*`` are not
+    required and not listed."""
+    t = model_cfg["transformer"]
+    vp = model_cfg["variance_predictor"]
+    out: "OrderedDict[str, tuple]" = OrderedDict()
+
+    def wb(prefix, *wshape):
+        out[prefix + ".weight"] = tuple(wshape)
+        out[prefix + ".bias"] = (wshape[0],)
+
+    def stack(prefix, n_layers, d):
+        for i in range(n_layers):
+            p = f"{prefix}.layer_stack.{i}"
+            for w in ("w_qs", "w_ks", "w_vs", "fc"):
+                wb(f"{p}.slf_attn.{w}", d, d)
+            out[f"{p}.slf_attn.layer_norm.weight"] = out[f"{p}.slf_attn.layer_norm.bias"] = (d,)
+            wb(f"{p}.pos_ffn.w_1", t["conv_filter_size"], d, t["conv_kernel_size"][0])
+            wb(f"{p}.pos_ffn.w_2", d, t["conv_filter_size"], t["conv_kernel_size"][1])
+            out[f"{p}.pos_ffn.layer_norm.weight"] = out[f"{p}.pos_ffn.layer_norm.bias"] = (d,)
+
+    d_enc, d_dec, n_bins = t["encoder_hidden"], t["decoder_hidden"], model_cfg["variance_embedding"]["n_bins"]
+    out["txt_encoder.src_word_emb.weight"] = (N_SYMBOLS + 1, d_enc)
+    stack("txt_encoder", t["encoder_layer"], d_enc)
+    out["variance_adaptor.pitch_bins"] = out["variance_adaptor.energy_bins"] = (n_bins - 1,)
+    F, K = vp["filter_size"], vp["kernel_size"]
+    for name in ("duration", "pitch", "energy"):
+        p = f"variance_adaptor.{name}_predictor"
+        wb(f"{p}.conv_layer.conv1d_1.conv", F, d_enc, K)
+        out[f"{p}.conv_layer.layer_norm_1.weight"] = out[f"{p}.conv_layer.layer_norm_1.bias"] = (F,)
+        wb(f"{p}.conv_layer.conv1d_2.conv", F, F, K)
+        out[f"{p}.conv_layer.layer_norm_2.weight"] = out[f"{p}.conv_layer.layer_norm_2.bias"] = (F,)
+        wb(f"{p}.linear_layer", 1, F)
+    out["variance_adaptor.pitch_embedding.weight"] = out["variance_adaptor.energy_embedding.weight"] = (n_bins, d_enc)
+    stack("mel_decoder", t["decoder_layer"], d_dec)
+    wb("mel_linear", N_MEL, d_dec)
+    chans = [N_MEL] + [POSTNET_DIM] * (POSTNET_N - 1) + [N_MEL]
+    for i in range(POSTNET_N):
+        wb(f"postnet.convolutions.{i}.0.conv", chans[i + 1], chans[i], POSTNET_K)
+        for s in ("weight", "bias", "running_mean", "running_var"):
+            out[f"postnet.convolutions.{i}.1.{s}"] = (chans[i + 1],)
+    return out
+
+
+def inference_keys(model_cfg: dict):
+    return list(inference_shapes(model_cfg))
+
+
+_NORM_KEY = re.compile(r"(.*\.layer_norm(_\d)?|postnet\.convolutions\.\d+\.1)\.(weight|bias|running_mean|running_var)")
+
+
 def default_init_state_dict(model_cfg: dict, stats: dict) -> "OrderedDict[str, np.ndarray]":
     """What the reference constructor leaves in the module (model/fastspeech2_align.py:16-28): every layer is a stock
     ``torch.nn`` module with torch's default initialiser — Linear / Conv1d ``kaiming_uniform_(a=sqrt(5))`` = U(+-1/sqrt(fan_in))
@@ -235,28 +288,26 @@ def default_init_state_dict(model_cfg: dict, stats: dict) -> "OrderedDict[str, n
     equal).  Bins come from ``stats.json`` (model/modules.py:41-71).  Inference subset only (no ``mel_encoder``)."""
     import torch
 
-    sd = synth_state_dict(model_cfg, seed=0, stats=stats)  # key set and shapes; every value is overwritten below
+    shapes = inference_shapes(model_cfg)
     pb, eb = variance_bins(model_cfg, stats)
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
-    for k, v in sd.items():
-        if k.endswith("position_enc") or k.endswith("num_batches_tracked"):
-            out[k] = v
-        elif k.endswith("pitch_bins"):
+    for k, shape in shapes.items():
+        if k.endswith("pitch_bins"):
             out[k] = pb
         elif k.endswith("energy_bins"):
             out[k] = eb
-        elif "layer_norm" in k or ".1." in k and k.startswith("postnet."):  # LayerNorm / BatchNorm1d
+        elif _NORM_KEY.fullmatch(k):  # LayerNorm / BatchNorm1d parameters and running statistics — and nothing else
             one = k.endswith(".weight") or k.endswith("running_var")
-            out[k] = np.full(v.shape, 1.0 if one else 0.0, dtype=np.float32)
+            out[k] = np.full(shape, 1.0 if one else 0.0, dtype=np.float32)
         elif k.endswith("embedding.weight") or k.endswith("src_word_emb.weight"):
-            e = torch.randn(*v.shape).numpy()
+            e = torch.randn(*shape).numpy()
             if k.endswith("src_word_emb.weight"):
                 e[0] = 0.0  # padding_idx
             out[k] = e
         else:  # Linear [out, in] / Conv1d [out, in, k] weight, or their bias [out] (fan_in from the matching weight)
-            w = sd[k[:-len(".bias")] + ".weight"] if k.endswith(".bias") else v
-            bound = 1.0 / math.sqrt(int(np.prod(w.shape[1:])))
-            out[k] = torch.empty(*v.shape).uniform_(-bound, bound).numpy()
+            w = shapes[k[:-len(".bias")] + ".weight"] if k.endswith(".bias") else shape
+            bound = 1.0 / math.sqrt(int(np.prod(w[1:])))
+            out[k] = torch.empty(*shape).uniform_(-bound, bound).numpy()
     return out
 
 

@@ -111,6 +111,54 @@ def test_bench_one_rank_over_rccl():
     assert d["devices"] == [{"rank": 0, "device": "cuda:0", "name": d["devices"][0]["name"]}] and d["value"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_torchrun_form_with_8_ranks_sets_its_own_environment():
+    """The driver's documented N > 1 form — `python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8` —
+    never passes through bench.py's self_launch(), so whatever the ranks need must be set by the ranks themselves before
+    torch / HIP / RCCL load.  Run exactly that form with 8 ranks on the one-GPU rig from an environment that LACKS
+    HSA_ENABLE_IPC_MODE_LEGACY and OMP_NUM_THREADS and check that every rank reports them, plus its own step time,
+    T_pad and frame count (load imbalance across shards must be visible in a SCALE line)."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    e = dict(os.environ, NS_BENCH_ONE_GPU="1")
+    for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+              "NS_BENCH_LAUNCHER"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--no-extras"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=e)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["world_size_seen_by_rccl"] == 8 and d["one_gpu_rig"] is True
+    pr = d["per_rank"]
+    assert [x["rank"] for x in pr] == list(range(8))
+    assert all(x["hsa_ipc_mode_legacy"] == "0" and x["omp_num_threads"] == "8" and x["launcher"] == "torchrun" for x in pr), pr
+    assert all(x["ms_per_step"] > 0 and x["T_pad"] > 900 and x["valid_frames"] > 0 for x in pr)
+    assert sum(x["valid_frames"] for x in pr) == d["config"]["valid_frames_per_step"] and d["config"]["global_batch"] == 128
+    assert max(x["ms_per_step"] for x in pr) <= d["ms_per_step"] * 1.0001
+
+
+def test_rank_env_is_set_before_torch_loads():
+    """CPU: importing bench.py as a rank of a multi-process job sets the variables RCCL needs on this driver, from the
+    ranks' own process (both launch forms), without overriding what the launcher exported."""
+    code = ("import os, sys; sys.argv=['bench.py']; import importlib.util as u; "
+            "s=u.spec_from_file_location('_b', %r); m=u.module_from_spec(s); "
+            "import builtins; real=builtins.__import__\n"
+            "def spy(name, *a, **k):\n"
+            "    if name == 'torch' and 'seen' not in os.environ: os.environ['seen'] = os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', 'unset') + '/' + os.environ.get('OMP_NUM_THREADS', 'unset')\n"
+            "    return real(name, *a, **k)\n"
+            "builtins.__import__ = spy; s.loader.exec_module(m); print(os.environ['seen'])") % os.path.join(ROOT, "bench.py")
+    base = {k: v for k, v in os.environ.items() if k not in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS", "WORLD_SIZE")}
+    for extra, want in (({"WORLD_SIZE": "8"}, "0/8"), ({}, "0/unset"), ({"WORLD_SIZE": "2", "OMP_NUM_THREADS": "3"}, "0/3"),
+                        ({"HSA_ENABLE_IPC_MODE_LEGACY": "1"}, "1/unset")):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(base, **extra))
+        assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == want, (extra, r.stdout, r.stderr[-800:])
+
+
 def test_self_launch_command_line(monkeypatch):
     """CPU: the re-exec command is the driver's own torchrun form (one node, N ranks, 127.0.0.1 rendezvous)."""
     import importlib.util

@@ -79,6 +79,14 @@ def test_set_weight_validates_keys_and_shapes(lib):
     # training-only aligner weights and BN counters are accepted and ignored
     assert setw("mel_encoder.prenet.w_1.weight", a) == 0
     assert setw("postnet.convolutions.0.1.num_batches_tracked", np.zeros((), np.float32)) == 0
+    # ns_check_weight: the same verdicts without staging anything
+    def chk(name, arr):
+        return so.ns_check_weight(h, name.encode(), (C.c_int64 * arr.ndim)(*arr.shape), arr.ndim)
+
+    assert chk("mel_linear.weight", a) == 0 and chk("mel_encoder.prenet.w_1.weight", a) == 0
+    assert chk("mel_linear.weight", a[:, :100]) != 0 and "size mismatch" in so.ns_last_error().decode()
+    assert chk("mel_linear.weight", a.reshape(-1)) != 0 and "rank mismatch" in so.ns_last_error().decode()
+    assert chk("no.such.key", a) != 0 and "unexpected key" in so.ns_last_error().decode()
     # finalize without an arena / with missing keys fails loudly (host-side checks come first)
     assert so.ns_finalize_weights(h, None) != 0 and "arena" in so.ns_last_error().decode()
     so.ns_destroy(h)
@@ -200,6 +208,32 @@ def test_load_state_dict_rejects_bad_keys_without_poisoning(tmp_path, monkeypatc
     assert len(m._sd) == 0
     m.load_state_dict(good)
     assert m._loaded and calls == ["upload"] and "not.a.key" not in m._sd
+    # a rejected load on an ALREADY LOADED model must not touch native state (every successful
+    # ns_set_weight overwrites a staging buffer and marks the handle not-ready): no staging call, no upload
+    staged = []
+    real_stage = FastSpeech2Align._stage
+    monkeypatch.setattr(FastSpeech2Align, "_stage", lambda self, k, a: staged.append(k) or real_stage(self, k, a))
+    before = {k: v.copy() for k, v in m._sd.items()}
+    for bad, msg in (({"not.a.key": np.zeros(3, np.float32)}, "unexpected key"),
+                     ({"mel_linear.bias": np.zeros(81, np.float32)}, "size mismatch")):
+        with pytest.raises(RuntimeError, match=msg):
+            m.load_state_dict(dict({"mel_linear.weight": np.ones((80, 256), np.float32)}, **bad))
+    assert staged == [] and calls == ["upload"] and all(np.array_equal(before[k], m._sd[k]) for k in before)
+    # strict=False: the unexpected key is skipped and reported, the rest is loaded (nn.Module.load_state_dict semantics)
+    missing, unexpected = m.load_state_dict({"mel_linear.bias": np.full(80, 0.5, np.float32), "not.a.key": np.zeros(3, np.float32)}, strict=False)
+    assert missing == [] and unexpected == ["not.a.key"] and (m._sd["mel_linear.bias"] == 0.5).all() and calls == ["upload", "upload"]
+    calls.pop()
+    # a first load that lacks keys: strict raises naming them, strict=False fills them like the constructor would
+    m2 = FastSpeech2Align(wl.preprocess_config(), cfg)
+    m2._device = torch.device("cuda", 0)
+    part = {k: v for k, v in good.items() if not k.startswith("mel_linear.")}
+    with pytest.raises(RuntimeError, match="missing key.*mel_linear.weight"):
+        m2.load_state_dict(part)
+    assert not m2._loaded
+    m2._stats = wl.SYNTH_STATS
+    m2.load_state_dict(part, strict=False)
+    assert m2._loaded and m2._sd["mel_linear.weight"].shape == (80, 256) and m2._sd["mel_linear.weight"].std() > 0
+    calls.pop()
     m._arena = object()
     m.to(torch.device("cuda", 1))  # device change: never keep the old device's arena bound
     assert calls == ["upload", "bind", "upload"] and m._device == torch.device("cuda", 1) and len(m._ws) == 0
@@ -233,8 +267,15 @@ def test_default_init_state_dict_follows_torch_initialisers():
     a = wl.default_init_state_dict(cfg, wl.SYNTH_STATS)
     torch.manual_seed(3)
     b = wl.default_init_state_dict(cfg, wl.SYNTH_STATS)
-    ref = wl.synth_state_dict(cfg)
-    assert list(a) == list(ref) and all(a[k].shape == ref[k].shape for k in a)
+    ref = {k: v for k, v in wl.synth_state_dict(cfg).items() if not k.endswith("position_enc") and not k.endswith("num_batches_tracked")}
+    assert set(a) == set(ref) == set(wl.inference_shapes(cfg)) and all(a[k].shape == ref[k].shape for k in a)
+    # every Linear / Conv1d weight AND bias is a random draw — only LayerNorm / BatchNorm entries may be constant
+    # (round 2 matched ".1." as a substring and turned PostNet conv 1 into all-ones)
+    for k, v in a.items():
+        is_norm = "layer_norm" in k or re.fullmatch(r"postnet\.convolutions\.\d+\.1\..*", k)
+        if v.size > 1 and not is_norm and not k.endswith("_bins"):
+            assert v.min() != v.max(), f"{k} is constant"
+    assert np.abs(a["postnet.convolutions.1.0.conv.weight"]).max() <= 1 / np.sqrt(512 * 5) and a["postnet.convolutions.1.0.conv.weight"].std() > 0.01
     assert all(np.array_equal(a[k], b[k]) for k in a)
     w = a["mel_decoder.layer_stack.0.pos_ffn.w_1.weight"]  # Conv1d [1024, 256, 9]: U(+-1/sqrt(256*9))
     assert w.shape == (1024, 256, 9) and 0.99 / 48 < np.abs(w).max() <= 1 / 48

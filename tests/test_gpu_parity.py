@@ -310,7 +310,7 @@ def _oracle_case_with_margin(w, cfg, B, L, seed, lens=None, margin=2e-4, tries=4
     raise AssertionError(f"no input seed in [{seed}, {seed + tries}) keeps every duration {margin} away from a rounding boundary")
 
 
-def _screened_full_batch(w, cfg, B, L, seed, margin=2e-4):
+def _screened_full_batch(w, cfg, B, L, seed, margin=2e-4, lens_fn=None, **oracle_kw):
     """Full-size configs: the oracle forward takes 2-20 s there, so instead of re-drawing whole batches, screen 2*B candidate
     utterances with the oracle's encoder + duration predictor only (7 % of the flops; an unpadded utterance's durations
     depend on its own tokens alone) and keep the first B whose durations all sit >= margin away from a
@@ -318,7 +318,9 @@ def _screened_full_batch(w, cfg, B, L, seed, margin=2e-4):
     import smart_nar_fast_tts_amd.workload as wl
     from oracle import fs2_oracle as orc
 
-    sp, tx, ln, Lmax = wl.synth_inputs(2 * B, L, seed=seed)
+    # lens_fn(n) -> n phoneme counts (ragged batches); a padded utterance's durations still depend on its own tokens and
+    # on L alone (key mask + zeroed pad rows), so the per-utterance screen stays valid
+    sp, tx, ln, Lmax = wl.synth_inputs(2 * B, L, seed=seed, src_lens=None if lens_fn is None else lens_fn(2 * B))
     t = cfg["transformer"]
     keep = []
     with torch.no_grad():
@@ -327,13 +329,13 @@ def _screened_full_batch(w, cfg, B, L, seed, margin=2e-4):
             mask = orc.get_mask_from_lengths(lnc, Lmax)
             x = orc.txt_encoder(w, txc, mask, t["encoder_head"], cfg["max_seq_len"])
             hd = _half_dist(orc.variance_predictor(w, "variance_adaptor.duration_predictor", x, mask).numpy())
-            keep += [lo + i for i in range(hd.shape[0]) if hd[i].min() >= margin]
+            keep += [lo + i for i in range(hd.shape[0]) if hd[i][:int(lnc[i])].min() >= margin]
     assert len(keep) >= B, f"only {len(keep)} of {2 * B} candidate utterances keep {margin} from the rounding boundaries"
     keep = keep[:B]
     inp = (sp[keep], np.ascontiguousarray(tx[keep]), ln[keep], Lmax)
     with torch.no_grad():
-        ref = orc.forward(w, cfg, torch.from_numpy(inp[0]), torch.from_numpy(inp[1]), torch.from_numpy(inp[2]), Lmax)
-    assert _half_dist(ref[4].numpy()).min() >= margin / 2
+        ref = orc.forward(w, cfg, torch.from_numpy(inp[0]), torch.from_numpy(inp[1]), torch.from_numpy(inp[2]), Lmax, **oracle_kw)
+    assert _half_dist(ref[4].numpy())[~ref[6].numpy()].min() >= margin / 2
     return inp, ref
 
 
@@ -405,6 +407,66 @@ def test_full_size_cfg4_cfg5_vs_oracle(workload):
     print(workload, "B", B, "L", L, "T_pad", out[0].shape[1], "rows", B * out[0].shape[1], "valid frames", int(ref[9].sum()), r)
     assert out[0].shape[0] == B and (out[0].shape[1] > 3000 if workload == "cfg5_longform" else B * out[0].shape[1] > 60000)
     _MODEL.clear()  # 329 MB of d=512 weights + ~1 GB of scratch: give it back before the next test
+
+
+def test_cfg5_longform_gaussian_full_size_vs_oracle():
+    """BASELINE config 5 AS WORDED ("mel_len=4000, batch=8, Gaussian-upsample + variable-length masking stress"): the
+    reference's GaussianUpsampling (model/modules.py:166-192) wired in as the length regulator (the §8 f1 extension), B=8,
+    L=128, ~31 frames per phoneme -> T_pad ~3900, at FULL size, every frame of every output against the oracle with the
+    bucket decisions pinned.  (w = [8, 128, ~3900] Gaussian weights per forward; 122 key tiles per attention sweep.)"""
+    import smart_nar_fast_tts_amd.workload as wl
+    from oracle import fs2_oracle as orc
+
+    cfg_name, B, L, fpp = wl.WORKLOADS["cfg5_longform_gaussian"]
+    assert cfg_name.endswith("+gaussian") and B == 8
+    meta = dict(config="ljspeech", weight_seed=0, frames_per_phoneme=fpp, dur_weight_scale=0.25, length_regulator="gaussian")
+    cfg, sd, m = gpu_model_for(meta)
+    assert m._cfg.length_regulator == 1
+    w = orc.to_torch_weights(sd)
+    inp, ref = _screened_full_batch(w, cfg, B, L, seed=0, length_regulator="gaussian")
+    r = _pinned_vs_oracle(m, w, cfg, inp, ref, "cfg5_longform_gaussian")
+    out = r.pop("out")
+    T = out[0].shape[1]
+    print("cfg5_longform_gaussian B", B, "L", L, "T_pad", T, "mel_lens", out[9].cpu().tolist(), r)
+    assert out[0].shape[0] == 8 and T > 3000 and len(set(out[9].cpu().tolist())) > 1  # long-form AND variable lengths
+    # Gaussian regulator semantics at this size: frames past an utterance's own length are zeroed before the decoder,
+    # so pitch / energy there are exactly 0 and the mask marks them
+    pad = out[7].cpu().numpy()
+    assert pad.any() and np.all(out[2].cpu().numpy()[pad] == 0.0) and np.all(out[3].cpu().numpy()[pad] == 0.0)
+    # and it is NOT the hard regulator's output (the test would be vacuous if the switch were ignored)
+    _, _, mh = gpu_model(dict(config="ljspeech", weight_seed=0, frames_per_phoneme=fpp, dur_weight_scale=0.25))
+    with torch.no_grad():
+        hard = mh(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3], p_targets=ref[2].cuda(), e_targets=ref[3].cuda())
+    assert torch.equal(hard[9], out[9]) and float((hard[0] - out[0]).abs().max()) > 1e-2
+    _MODEL.clear()
+
+
+def test_cfg5_longform_ragged_vs_oracle():
+    """Config 5's "variable-length masking stress" on the reference's real path (hard LengthRegulator): B=8, phoneme counts
+    drawn in [L/8, L] with one utterance at L, 31 frames per phoneme -> T_pad ~3900 while the shortest utterances leave
+    thousands of padded frames (dozens of fully padded GEMM tiles, attention query AND key tiles, masked LayerNorm rows).
+    EVERY output row — padded ones included — against the oracle, bucket decisions pinned."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from oracle import fs2_oracle as orc
+
+    cfg_name, B, L, fpp = wl.WORKLOADS["cfg5_longform"]
+    meta = dict(config=cfg_name, weight_seed=0, frames_per_phoneme=fpp, dur_weight_scale=0.25)
+    cfg, sd, m = gpu_model(meta)
+    w = orc.to_torch_weights(sd)
+
+    def lens_fn(n):
+        ln = np.random.RandomState(11).randint(L // 8, L + 1, size=n)
+        ln[0::5] = L  # a few full-length candidates: whichever survives the screen sets T_pad ~ 3900
+        return ln
+
+    inp, ref = _screened_full_batch(w, cfg, B, L, seed=4, lens_fn=lens_fn)
+    assert inp[2].max() == L, "screening dropped every full-length utterance"
+    r = _pinned_vs_oracle(m, w, cfg, inp, ref, "cfg5_longform ragged")
+    out = r.pop("out")
+    lens = out[9].cpu().numpy()
+    print("cfg5_longform ragged: src_lens", inp[2].tolist(), "mel_lens", lens.tolist(), "T_pad", out[0].shape[1], r)
+    assert out[0].shape[1] > 3000 and lens.min() < out[0].shape[1] // 2  # long-form, and at least half of a row is padding
+    _MODEL.clear()
 
 
 def test_edge_cases():
@@ -534,7 +596,81 @@ def test_max_mel_len_global_pad_mode():
         if lens[b] < T:  # had padding before: unchanged
             assert torch.equal(padded[1][b, :lens[b]], base[1][b, :lens[b]])
     with pytest.raises(ValueError, match="smaller than the longest"):
-        m(dev(z["speakers"]), dev(z["texts"]), dev(z["in_src_lens"]), int(meta["L"]), max_mel_len=T - 1)
+        m(dev(z["speakers"]), dev(z["texts"]), dev(z["in_src_lens"]), int(meta["L"]), max_mel_len=lambda t: T - 1)
+
+
+def test_capacity_mode_is_sync_free_and_bit_identical():
+    """max_mel_len=<int> (model/modules.py:128-131,204-213 `max_len` semantics): phase 2 is enqueued right behind phase 1,
+    nothing on the host waits for mel_lens.  With the capacity equal to the longest utterance every output is BIT-identical
+    to the synchronous path; what the synchronous path raises on the spot arrives through check_status()."""
+    from unittest import mock
+
+    from smart_nar_fast_tts_amd import _lib
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    meta, z = load_golden("e2e_tiny_padded_src")
+    cfg, sd, m = gpu_model(meta)
+    base = run_gpu(m, z, meta)
+    T = base[0].shape[1]
+    args = (dev(z["speakers"]), dev(z["texts"]), dev(z["in_src_lens"]), int(meta["L"]))
+    with torch.no_grad(), mock.patch.object(FastSpeech2Align, "_wait_phase1", side_effect=AssertionError("host waited")), \
+            mock.patch.object(torch.cuda.Event, "synchronize", side_effect=AssertionError("host waited")), \
+            mock.patch.object(torch.cuda, "synchronize", side_effect=AssertionError("host waited")):
+        cap = m(*args, max_mel_len=T)   # would raise if the forward waited for phase 1 in any way
+    assert m.check_status() == [0] * len(z["in_src_lens"])
+    for i in (0, 1, 2, 3, 4, 5, 6, 7, 9):
+        assert torch.equal(cap[i], base[i]), NAMES[i]
+    # a larger capacity: same as the synchronous padded run
+    with torch.no_grad():
+        cap9 = m(*args, max_mel_len=T + 9)
+        ref9 = m(*args, max_mel_len=lambda t: int(t) + 9)
+    assert all(torch.equal(cap9[i], ref9[i]) for i in (0, 1, 2, 3, 7, 9)) and m.check_status() == [0] * len(z["in_src_lens"])
+    # too small a capacity: every utterance longer than it is reported, the others are bit-identical to a run at that padding
+    lens = base[9].cpu().numpy()
+    Tcut = int(np.sort(lens)[-2]) if len(lens) > 1 and np.sort(lens)[-2] < T else T - 1
+    with torch.no_grad():
+        cut = m(*args, max_mel_len=Tcut)
+    words = m.last_status.cpu().numpy()
+    assert np.array_equal(words & _lib.STATUS_TRUNCATED, (lens > Tcut).astype(np.int32)) and cut[0].shape[1] == Tcut
+    assert torch.isfinite(cut[1]).all() and torch.equal(cut[9], base[9])
+    with pytest.raises(ValueError, match="cut off"):
+        m.check_status()
+    # a bad token id: the synchronous path raises IndexError on the spot, capacity mode through check_status()
+    bad = z["texts"].copy()
+    bad[0, 0] = 100000
+    with pytest.raises(IndexError):
+        m(args[0], dev(bad), args[2], args[3])
+    with torch.no_grad():
+        m(args[0], dev(bad), args[2], args[3], max_mel_len=T)
+    assert m.last_status.cpu().numpy()[0] & _lib.STATUS_BAD_TOKEN
+    with pytest.raises(IndexError):
+        m.check_status()
+    # the C-ABI refuses to run without a status buffer (a C caller cannot truncate silently)
+    rc = m._lib.ns_forward_mel(m._h, 1, 1, 1, None, 1.0, 1.0, None, None, None, None, 0, None, None, None, None, None, None, None)
+    assert rc != 0 and b"status" in m._lib.ns_last_error()
+
+
+def test_rejected_state_dict_leaves_the_loaded_model_usable():
+    """load good weights, attempt a bad load (unexpected key / wrong shape), then run — the forward
+    still works and its output is bit-identical to before."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    meta, z = load_golden("e2e_tiny_padded_src")
+    cfg, sd = weights_for(meta)
+    m = FastSpeech2Align(wl.preprocess_config(), cfg).to("cuda").eval()
+    m.load_state_dict(sd)
+    before = run_gpu(m, z, meta)
+    for bad, msg in (({"not.a.key": np.zeros(3, np.float32)}, "unexpected key"),
+                     ({"mel_linear.bias": np.zeros(81, np.float32)}, "size mismatch")):
+        with pytest.raises(RuntimeError, match=msg):
+            m.load_state_dict(dict({"mel_linear.weight": np.ones((80, 256), np.float32)}, **bad))
+    after = run_gpu(m, z, meta)
+    assert torch.equal(before[1], after[1]) and torch.equal(before[9], after[9])
+    # and a partial (valid) update does take effect
+    m.load_state_dict({"mel_linear.bias": np.asarray(sd["mel_linear.bias"]) + 1.0})
+    moved = run_gpu(m, z, meta)
+    assert torch.allclose(moved[0], before[0] + 1.0, atol=1e-5)
 
 
 def test_random_shapes_vs_oracle():
