@@ -475,7 +475,7 @@ static int gemm_ln(const float* X, int ldx, const float* W, const float* bias, c
     return 0;
   }
   if (fuse_row_epilogue(M, N, Cin)) return gemm(X, ldx, W, bias, resid, N, Y, N, M, N, Cin, KW, S, act, st, &e, EPI_LN, Wb3);
-  if (Cin % 32 == 0 && N % 4 == 0 && N <= 1024 && (e.ticket = sc.take_tickets(conv_gemm_ticket_ints(M))) != nullptr) {
+  if (conv_gemm_ticket_ok(M, N, Cin) && (e.ticket = sc.take_tickets(conv_gemm_ticket_ints(M))) != nullptr) {
     e.y_out = Y;
     return gemm(X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st, &e, EPI_LN);
   }
@@ -584,7 +584,7 @@ static int predictor(const ns_model* m, const PredW& w, const float* x, const lo
   e.D = w.cin;
   if (fuse_row_epilogue(M, F, F))
     return gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, nullptr, F, M, F, F, c.vp_kernel, S, ACT_RELU, st, &e, EPI_LN_PRED);
-  if (F % 32 == 0 && F <= 1024 && (e.ticket = sc.take_tickets(conv_gemm_ticket_ints(M))) != nullptr)
+  if (conv_gemm_ticket_ok(M, F, F) && (e.ticket = sc.take_tickets(conv_gemm_ticket_ints(M))) != nullptr)
     return gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st, &e, EPI_LN_PRED);
   NS_TRY(gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st));
   NS_HIP(launch_ln_linear_embed(sc.vp1, m->P(w.ln2_g), m->P(w.ln2_b), m->P(w.lin_w), m->P(w.lin_b), pred, M, F, S, lens,

@@ -30,7 +30,9 @@ namespace ns {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr int ATT_STRIP_SPLIT_MAX = 8;  // workgroups sharing one 32-query strip's key axis (k_attention_strip)
 
 template <int DK>
 __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, const long long* __restrict__ lens,
@@ -505,20 +507,28 @@ __global__ __launch_bounds__(256) void k_attention_strip(const float* __restrict
     if (q < S) pieces(1.0f / l_all, out + ((size_t)b * S + q) * d + hd * DK + 4 * h);  // lens[b]==0 -> 0 * inf = NaN, as the reference
     return;
   }
-  // ---- several workgroups share this strip: publish the un-normalised partial, the last arriver merges in split order
+  // ---- several workgroups share this strip: publish the un-normalised partial, the last arriver merges in split order.
+  // Partials travel as 16-byte write-through (sc1) stores and are read back with sc1 loads — all splits' loads in flight at
+  // once — so neither side needs a cache write-back / invalidate fence.
   const size_t Mrows = (size_t)gridDim.z * S;
   const int H = gridDim.y;
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)opart, (short)0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsML = __builtin_amdgcn_make_buffer_rsrc((void*)mlpart, (short)0, 0x7FFFFFFF, 0x00020000);
+  const int qc = q < S ? q : S - 1;  // rows past S: read / write nothing that matters (stores are predicated)
+  auto orow = [&](int s2) { return (int)((((size_t)s2 * Mrows + (size_t)b * S + qc) * d + hd * DK + 4 * h + 8 * NDB * u) * 4); };
+  auto mlrow = [&](int s2) { return (int)(((((size_t)s2 * Mrows + (size_t)b * S + qc) * H + hd) * 2) * 4); };
   if (q < S) {
-    const size_t row = (size_t)sp * Mrows + (size_t)b * S + q;
-    float* dst = opart + row * d + hd * DK + 4 * h + 8 * NDB * u;
 #pragma unroll
-    for (int pj = 0; pj < NDB; ++pj)
+    for (int pj = 0; pj < NDB; ++pj) {
+      f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        __hip_atomic_store(dst + 8 * pj + e, mo[e % NDB][pj * JP + e / NDB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1
+      for (int e = 0; e < 4; ++e) v[e] = mo[e % NDB][pj * JP + e / NDB];
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO, orow(sp) + 32 * pj, 0, 16 /* sc1 */);
+    }
     if (u == 0 && h == 0) {
-      __hip_atomic_store(mlpart + (row * H + hd) * 2, m_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(mlpart + (row * H + hd) * 2 + 1, l_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{m_all, l_all}), rsML, mlrow(sp), 0, 16);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -528,24 +538,36 @@ __global__ __launch_bounds__(256) void k_attention_strip(const float* __restrict
     *last = __hip_atomic_fetch_add(tickets + ((size_t)b * H + hd) * nstrips + strip, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1;
   __syncthreads();
   if (!*last) return;
-  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  __syncthreads();
-  if (q >= S) return;
+  // every split's (m, l) and O pieces requested up front; splits past nsplit re-read split 0 with weight 0
+  typedef unsigned u32x2b __attribute__((ext_vector_type(2)));
+  typedef float f32x2b __attribute__((ext_vector_type(2)));
+  f32x2b ml2[ATT_STRIP_SPLIT_MAX];
+  f32x4 op[ATT_STRIP_SPLIT_MAX][NDB];
+#pragma unroll
+  for (int s2 = 0; s2 < ATT_STRIP_SPLIT_MAX; ++s2) {
+    const int sc2 = s2 < nsplit ? s2 : 0;
+    ml2[s2] = __builtin_bit_cast(f32x2b, __builtin_amdgcn_raw_buffer_load_b64(rsML, mlrow(sc2), 0, 16));
+#pragma unroll
+    for (int pj = 0; pj < NDB; ++pj) op[s2][pj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsO, orow(sc2) + 32 * pj, 0, 16));
+  }
   float mx = -INFINITY;
-  for (int s2 = 0; s2 < nsplit; ++s2) mx = fmaxf(mx, mlpart[((s2 * Mrows + (size_t)b * S + q) * H + hd) * 2]);
+#pragma unroll
+  for (int s2 = 0; s2 < ATT_STRIP_SPLIT_MAX; ++s2) mx = fmaxf(mx, s2 < nsplit ? ml2[s2][0] : -INFINITY);
   const float mx_use = (mx == -INFINITY) ? 0.f : mx;
   f32x4 acc[NDB];
 #pragma unroll
   for (int pj = 0; pj < NDB; ++pj) acc[pj] = f32x4{0.f, 0.f, 0.f, 0.f};
   float l = 0.f;
-  for (int s2 = 0; s2 < nsplit; ++s2) {
-    const size_t row = (size_t)s2 * Mrows + (size_t)b * S + q;
-    const float w2 = __builtin_amdgcn_exp2f(mlpart[(row * H + hd) * 2] - mx_use);
-    l += mlpart[(row * H + hd) * 2 + 1] * w2;
-    const float* src = opart + row * d + hd * DK + 4 * h + 8 * NDB * u;
 #pragma unroll
-    for (int pj = 0; pj < NDB; ++pj) acc[pj] += *reinterpret_cast<const f32x4*>(src + 8 * pj) * w2;
+  for (int s2 = 0; s2 < ATT_STRIP_SPLIT_MAX; ++s2) {
+    if (s2 < nsplit) {  // wave-uniform
+      const float w2 = __builtin_amdgcn_exp2f(ml2[s2][0] - mx_use);
+      l += ml2[s2][1] * w2;
+#pragma unroll
+      for (int pj = 0; pj < NDB; ++pj) acc[pj] += op[s2][pj] * w2;
+    }
   }
+  if (q >= S) return;
   const float inv = 1.0f / l;
   float* dst = out + ((size_t)b * S + q) * d + hd * DK + 4 * h + 8 * NDB * u;
 #pragma unroll
@@ -596,8 +618,9 @@ hipError_t launch_attention(const float* qkv, const long long* lens, int B, int 
     const long strips = (long)tiles * H * B;
     int nsplit = (int)((256 + strips - 1) / strips);
     if (nsplit > (tiles + 3) / 4) nsplit = (tiles + 3) / 4;   // at least one key tile per wave
-    if (nsplit > ATT_SPLIT_MAX) nsplit = ATT_SPLIT_MAX;
+    if (nsplit > ATT_STRIP_SPLIT_MAX) nsplit = ATT_STRIP_SPLIT_MAX;
     if (nsplit > 1 && (!scratch || !tickets)) nsplit = 1;
+    if (part_floats(nsplit) * 4 >= (1ull << 31)) nsplit = 1;  // 31-bit descriptor offsets over the partials
     while (nsplit > 1 && part_floats(nsplit) > scratch_floats) --nsplit;
     int tpr = (tiles + 4 * nsplit - 1) / (4 * nsplit);
     nsplit = ((tiles + tpr - 1) / tpr + 3) / 4;                // no workgroup of empty ranges

@@ -35,6 +35,7 @@
 namespace ns {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 [[maybe_unused]] constexpr int OOR = (int)0x80000000;  // voffset marker: beyond num_records -> the DMA writes zeros
@@ -47,7 +48,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // Visibility across the 8 XCDs' private L2s / the CUs' L1s: sc1 (write-through) tile stores, every storing wave drains
 // vmcnt, barrier, ONE relaxed agent-scope fetch_add; the last arriver does ONE agent-scope acquire, then plain loads
 // (cdna_hip_programming.md Guideline 16, counter form).  The counters are zeroed by the first kernel of the forward phase.
-template <int BM, int BN, int BK, int KS, int WGM = 2, int WGN = 2, bool ROWEPI = false, bool TICKET = false>
+template <int BM, int BN, int BK, int KS, int WGM = 2, int WGN = 2, bool ROWEPI = false, int TICKET = 0>  // TICKET: row width / 256, 0 = off
 __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, int ntn) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type does not exist in the host pass; it only needs the stub
   constexpr int NW = WGM * WGN;       // waves per K-split group, arranged WGM x WGN over the block tile
@@ -59,9 +60,6 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
   constexpr int FSH = (BK == 64) ? 0 : (BK == 32) ? 1 : 2;
   constexpr int FMSK = CPR - 1;
   static_assert(BK == 64 || BK == 32 || BK == 16, "BK");
-  // split-K partial tiles (BM*BN floats each) are parked in the two B staging objects, whole tiles per object
-  static_assert(KS == 1 || ((KS * BN * BK) / (BM * BN) >= 1 && (KS - 1) <= 2 * ((KS * BN * BK) / (BM * BN))),
-                "split-K partial tiles must fit the B staging buffers");
   static_assert(!ROWEPI || (KS == 1 && BM <= 2 * BK && BN % 256 == 0 && BM % (WGM * WGN) == 0), "row epilogue: the BM x BN tile is parked in the two B staging buffers");
   static_assert(!(ROWEPI && TICKET), "a full-row tile needs no ticket");
 
@@ -101,7 +99,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
   const int grp = wall / NW, wid = wall % NW;  // K-split group, wave inside the WGM x WGN arrangement
   const int wm0 = (wid / WGN) * WM, wn0 = (wid % WGN) * WN;
 
-  const int Kt = p.KW * p.Cin;
+  const int Kt = p.ldw ? p.ldw : p.KW * p.Cin;  // weight row stride: dense, or padded (see ConvGemm::ldw)
   const int cpj = p.Cin / BK;  // chunks per tap
   const int nch = p.KW * cpj;
 
@@ -219,39 +217,66 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
     if (st + 1 < nsteps) step(st + 1, A1, B1, A0, B0);
   }
 
-  if (KS > 1) {
-    // sum the K-split partial tiles: groups 1..KS-1 park their accumulators in the (now idle) B staging buffers,
-    // lane-linear, PER_OBJ whole tiles per LDS object (never straddling one); group 0 adds them in group order and runs
-    // the epilogue
-    constexpr int TILE = BM * BN;
-    constexpr int PER_OBJ = (KS * BN * BK) / TILE;
-    if (grp > 0) {
-      float* red = ((grp - 1) / PER_OBJ ? Bs1 : Bs0) + ((grp - 1) % PER_OBJ) * TILE;
+  const int ecol = lane & 31, erow = (lane >> 5) * 4;  // C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if constexpr (KS > 1) {
+    // K-split epilogue, ALL waves of the workgroup: every group parks its partial tile ROW-MAJOR in the (now idle) staging
+    // LDS — row stride BN + 8 floats, so the two lane halves of a store (rows 4 apart) land 32 banks apart — and after one
+    // barrier each thread owns float4 units of the output tile: it sums the KS partials in group order (the same order as
+    // before: bit-identical sums), adds bias / activation / residual and stores 16 bytes.  Bias and residual are float4 loads
+    // issued BEFORE the parking stores and the barrier, so their latency is hidden.  (Before: group 0 alone ran the epilogue
+    // element-wise — 16 scalar loads / stores per lane with the bias and residual latency exposed: ~3 us per launch, as long
+    // as the K loop of the short GEMMs; ~6.5 us with write-through stores.  tools/lab/README.md.)
+    constexpr int RS = BN + 8, TILE = BM * RS;
+    constexpr int PB = (KS * BN * BK) / TILE, PA = (KS * BM * BK) / TILE;
+    static_assert(2 * PB + 2 * PA >= KS, "the KS partial tiles must fit the four staging objects, whole tiles per object");
+    auto part = [&](int g) -> float* {
+      if (g < PB) return Bs0 + g * TILE;
+      if (g < 2 * PB) return Bs1 + (g - PB) * TILE;
+      if (g < 2 * PB + PA) return As0 + (g - 2 * PB) * TILE;
+      return As1 + (g - 2 * PB - PA) * TILE;
+    };
+    constexpr int NT = 64 * NW * KS, U = BM * BN / 4, UPT = (U + NT - 1) / NT, CPRW = BN / 4;
+    f32x4 bia[UPT], res[UPT];
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) {
+      const int u = tid + k * NT, row = u / CPRW, m = m0 + row, n = n0 + (u % CPRW) * 4;
+      const bool ok = u < U && m < p.M && n < p.N;
+      bia[k] = (ok && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      res[k] = (ok && p.resid) ? *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    {
+      float* mine = part(grp);
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) red[(((wid * TM + mi) * TN + ni) * 16 + r) * 64 + lane] = acc[mi][ni][r];
+          for (int r = 0; r < 16; ++r)
+            mine[(wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + erow) * RS + wn0 + ni * 32 + ecol] = acc[mi][ni][r];
     }
     __syncthreads();
-    if (!TICKET && grp > 0) return;  // (ticketed: the other groups' waves stay for the row phase below)
-    if (grp == 0) {
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsYs = __builtin_amdgcn_make_buffer_rsrc((void*)p.Y, (short)0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
-      for (int g2 = 1; g2 < KS; ++g2) {
-        const float* red = ((g2 - 1) / PER_OBJ ? Bs1 : Bs0) + ((g2 - 1) % PER_OBJ) * TILE;
+    for (int k = 0; k < UPT; ++k) {
+      const int u = tid + k * NT, row = u / CPRW, c4 = u % CPRW, m = m0 + row, n = n0 + c4 * 4;
+      if (u >= U || m >= p.M || n >= p.N) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(part(0) + row * RS + c4 * 4);
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
+      for (int g2 = 1; g2 < KS; ++g2) v += *reinterpret_cast<const f32x4*>(part(g2) + row * RS + c4 * 4);
+      v += bia[k];
+      if (p.act == ACT_RELU) {
 #pragma unroll
-          for (int ni = 0; ni < TN; ++ni)
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      } else if (p.act == ACT_TANH) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] += red[(((wid * TM + mi) * TN + ni) * 16 + r) * 64 + lane];
+        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
       }
+      if (p.resid) v += res[k];
+      if constexpr (TICKET != 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4g, v), rsYs, (m * p.ldy + n) * 4, 0, 16 /* sc1: write-through */);
+      else *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + n) = v;
     }
   }
 
-  // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int ecol = lane & 31, erow = (lane >> 5) * 4;
   if constexpr (ROWEPI) {
     // Full-row tile (BN == N): park act(acc + bias) as a row-major [BM][BN] tile in the (idle) first B staging buffer,
     // then every wave takes BM / waves whole rows — one row per wave64, float4 lanes — and runs the row kernel's own
@@ -311,7 +336,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
       }
     }
   } else {
-    if (!TICKET || grp == 0) {
+    if constexpr (KS == 1) {
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
       const int n = n0 + wn0 + ni * 32 + ecol;
@@ -349,61 +374,57 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
       if (tid == 0) *last = __hip_atomic_fetch_add(p.e.ticket + tile_m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ntn - 1;
       __syncthreads();
       if (!*last) return;
-      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __syncthreads();
-      constexpr int NV = 4;  // row widths up to 1024 (ln_moments / ln_store skip float4s past N)
-      for (int ml = wall; ml < BM; ml += NWALL) {
-        const int m = m0 + ml;
-        if (m >= p.M) break;
-        const int b = m / p.S, t = m - b * p.S;
-        const bool masked = p.e.lens && (long long)t >= p.e.lens[b];
-        if (p.epi == EPI_LN && masked) {
-          for (int c = lane * 4; c < p.N; c += 256) *reinterpret_cast<f32x4*>(p.e.y_out + (size_t)m * p.N + c) = f32x4{0.f, 0.f, 0.f, 0.f};
-          continue;
-        }
-        f32x4 v[NV];
+      // (no acquire fence: the rows are read with sc1 loads, which do not hit stale lines of this CU's L1 / this XCD's L2)
+      const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)p.Y, (short)0, p.M * p.ldy * 4, 0x00020000);
+      // this wave's rows: wall, wall + NWALL, ... (BM / NWALL of them), at most 8 at a time
+      constexpr int RPW = BM / NWALL, RB = RPW < 8 ? RPW : 8;
+      static_assert(BM % NWALL == 0 && RPW % RB == 0, "rows divide evenly over the waves");
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          const int c = lane * 4 + i * 256;
-          v[i] = c < p.N ? *reinterpret_cast<const f32x4*>(p.Y + (size_t)m * p.ldy + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        float mean, rstd;
-        ln_moments<NV>(v, p.N, lane, mean, rstd);
-        if (p.epi == EPI_LN) ln_store<NV>(v, p.N, lane, mean, rstd, p.e.ln_g, p.e.ln_b, p.e.y_out + (size_t)m * p.N);
-        else predictor_row_tail<NV>(v, p.N, lane, mean, rstd, p.e, m, t, masked);
-      }
+      for (int j0 = 0; j0 < RPW; j0 += RB)
+        row_epilogue_batch<TICKET, RB>(rsY, p.ldy, lane, p.epi, p.e, p.M, p.S, m0 + wall + j0 * NWALL, NWALL);
     }
   }
 #endif
 }
 
-template <int BM, int BN, int BK, int KS = 1, int WGM = 2, int WGN = 2, bool ROWEPI = false, bool TICKET = false>
+template <int BM, int BN, int BK, int KS = 1, int WGM = 2, int WGN = 2, bool ROWEPI = false, int TICKET = 0>
 static hipError_t launch_t(const ConvGemm& p, hipStream_t st) {
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   hipLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN, ROWEPI, TICKET>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, p, ntn);
   return hipGetLastError();
 }
 
+bool conv_gemm_ticket_ok(int M, int N, int Cin) {
+  return M > 0 && (N == 256 || N == 512) && Cin % 32 == 0 && (long long)M * N * 4 < (1ll << 31);
+}
+
 bool conv_gemm_row_epilogue_ok(int M, int N, int Cin) {
   return M > 0 && (N == 256 || N == 512) && Cin % 32 == 0;
 }
 
-hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) {
+hipError_t launch_conv_gemm(const ConvGemm& p_in, hipStream_t st) {
+  ConvGemm p = p_in;
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
-  if (p.Cin % 16 != 0 || (p.ldx & 3) != 0) return hipErrorInvalidValue;
+  if (p.ldw == 0) p.ldw = p.KW * p.Cin;
+  if (p.Cin % 16 != 0 || (p.ldx & 3) != 0 || (p.ldw & 3) != 0 || p.ldw < p.KW * p.Cin) return hipErrorInvalidValue;
+  if ((p.N & 3) != 0 || (p.ldy & 3) != 0 || (p.resid && (p.ldr & 3) != 0)) return hipErrorInvalidValue;  // float4 epilogues
   // descriptor offsets are 31-bit: a tile's rows (BM + KW) * ldx and BN * K floats must stay below 2^29 floats
-  if ((long long)(256 + p.KW) * p.ldx >= (1ll << 29) || (long long)512 * p.KW * p.Cin >= (1ll << 29)) return hipErrorInvalidValue;
+  if ((long long)(256 + p.KW) * p.ldx >= (1ll << 29) || (long long)512 * p.ldw >= (1ll << 29)) return hipErrorInvalidValue;
   if (p.epi != EPI_NONE && p.e.ticket) {
     // ticketed row epilogue on the small-grid ladder (same tile choices as below): the smallest tile that still gives about
-    // one workgroup per CU, the rest of the CU spent on an in-workgroup K split
-    if (p.Cin % 32 || p.N % 4 || p.N > 1024 || p.ldy != p.N || (p.resid && (p.ldr & 3)) || (p.epi == EPI_LN && !p.e.y_out)) return hipErrorInvalidValue;
+    // one workgroup per CU, the rest of the CU spent on an in-workgroup K split.  Row widths 256 and 512.
+    if (!conv_gemm_ticket_ok(p.M, p.N, p.Cin) || p.ldy != p.N || (p.resid && (p.ldr & 3)) || (p.epi == EPI_LN && !p.e.y_out)) return hipErrorInvalidValue;
     const long rows32 = (p.M + 31) / 32;
     auto wgs = [&](long rows, int bn) { return rows * ((p.N + bn - 1) / bn); };
     const int nch = p.KW * (p.Cin / 32);
-    if (wgs(rows32, 32) <= 256) return nch >= 16 ? launch_t<32, 32, 32, 8, 1, 1, false, true>(p, st) : launch_t<32, 32, 32, 4, 1, 1, false, true>(p, st);
-    if (wgs(rows32, 64) <= 256) return launch_t<32, 64, 32, 4, 1, 2, false, true>(p, st);
-    if (wgs(rows32, 128) <= 512) return launch_t<32, 128, 32, 2, 1, 4, false, true>(p, st);
-    return launch_t<64, 64, 32, 1, 2, 2, false, true>(p, st);
+#define NS_TICKET_LADDER(NVT)                                                                                                        \
+    if (wgs(rows32, 32) <= 256) return nch >= 16 ? launch_t<32, 32, 32, 8, 1, 1, false, NVT>(p, st) : launch_t<32, 32, 32, 4, 1, 1, false, NVT>(p, st); \
+    if (wgs(rows32, 64) <= 256) return launch_t<32, 64, 32, 4, 1, 2, false, NVT>(p, st);                                             \
+    if (wgs(rows32, 128) <= 512) return launch_t<32, 128, 32, 2, 1, 4, false, NVT>(p, st);                                           \
+    return launch_t<64, 64, 32, 1, 2, 2, false, NVT>(p, st);
+    if (p.N == 256) { NS_TICKET_LADDER(1) }
+    NS_TICKET_LADDER(2)
+#undef NS_TICKET_LADDER
   }
   if (p.epi != EPI_NONE) {
     // full-row tile: 32 rows x N columns, N / 32 waves side by side with one 32x32 MFMA tile each

@@ -28,12 +28,14 @@ struct RowEpilogue {
   float* y_out; int* ticket;
 };
 inline int conv_gemm_ticket_ints(int M) { return (M + 31) / 32; }
+bool conv_gemm_ticket_ok(int M, int N, int Cin);  // shapes the ticketed form covers (row widths 256 / 512)
 
 // Y[m, n] = act( sum_{j<KW} sum_{c<Cin} X[m + j - pad, c] * W[n][j*Cin + c] + bias[n] ) + resid[m, n]
 // rows of X outside the utterance's [0, S) window read as zero ("same" zero padding of nn.Conv1d).
 struct ConvGemm {
   const float* X; int ldx;
-  const float* W;               // packed [N][KW*Cin]
+  const float* W;               // packed [N][KW*Cin], row stride ldw
+  int ldw;                      // floats between weight rows; 0 = KW*Cin (dense)
   const unsigned short* Wb3;    // optional: the same weights as three bf16 planes [3][N][KW*Cin] (gemm_bf16x3.hip), else nullptr
   const float* bias;            // [N] or nullptr
   const float* resid; int ldr;  // [M, N] or nullptr

@@ -8,16 +8,52 @@ namespace ns {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Wave64 all-lanes sum as a butterfly over lane distances 1, 2, 4, 8 (DPP: quad permutes, half-row mirror, row mirror — a
+// mirror pairs each lane with a lane of the neighbouring group, whose members all hold that group's sum by then), 16
+// (ds_swizzle) and 32 (two v_readlane).  Six dependent ds_bpermute_b32 (what __shfl_xor compiles to, ~70 cycles each with
+// its lgkmcnt wait) cost ~420 cycles per reduction; this is ~60.  Every lane ends with the same bits.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, SWZ_XOR16 = 0x401F;
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_f<DPP_XOR1>(v);
+  v += dpp_f<DPP_XOR2>(v);
+  v += dpp_f<DPP_HALF_MIRROR>(v);
+  v += dpp_f<DPP_MIRROR>(v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), SWZ_XOR16));
+  const int iv = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
 }
 
+__device__ __forceinline__ int wave_sum(int v) {
+  v += dpp_i<DPP_XOR1>(v);
+  v += dpp_i<DPP_XOR2>(v);
+  v += dpp_i<DPP_HALF_MIRROR>(v);
+  v += dpp_i<DPP_MIRROR>(v);
+  v += __builtin_amdgcn_ds_swizzle(v, SWZ_XOR16);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 32);
+}
+
+__device__ __forceinline__ double join_d(unsigned lo, unsigned hi) { return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  return join_d((unsigned)dpp_i<CTRL>((int)(unsigned)b), (unsigned)dpp_i<CTRL>((int)(unsigned)(b >> 32)));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_d<DPP_XOR1>(v);
+  v += dpp_d<DPP_XOR2>(v);
+  v += dpp_d<DPP_HALF_MIRROR>(v);
+  v += dpp_d<DPP_MIRROR>(v);
+  unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  v += join_d((unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)b, SWZ_XOR16), (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)(b >> 32), SWZ_XOR16));
+  b = __builtin_bit_cast(unsigned long long, v);
+  const int lo = (int)(unsigned)b, hi = (int)(unsigned)(b >> 32);
+  return join_d((unsigned)__builtin_amdgcn_readlane(lo, 0), (unsigned)__builtin_amdgcn_readlane(hi, 0)) +
+         join_d((unsigned)__builtin_amdgcn_readlane(lo, 32), (unsigned)__builtin_amdgcn_readlane(hi, 32));
 }
 
 constexpr float LN_EPS = 1e-5f;  // torch.nn.LayerNorm default
@@ -27,9 +63,7 @@ constexpr float LN_EPS = 1e-5f;  // torch.nn.LayerNorm default
 __device__ __forceinline__ int wave_bucketize(const float* __restrict__ bins, int n_edges, float v, int lane) {
   int cnt = 0;
   for (int k = lane; k < n_edges; k += 64) cnt += !(bins[k] >= v) ? 1 : 0;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-  return cnt;
+  return wave_sum(cnt);
 }
 
 // mean / rstd of one row held as up to NV float4 per lane (column c = lane*4 + i*256; entries at c >= C must be zero).
@@ -84,9 +118,9 @@ __device__ __forceinline__ void ln_store(const f32x4 (&v)[NV], int C, int lane, 
 // to the convolution that produced it), so that this tail adds no rounding of its own to the distance from the reference's
 // value — what remains is the fp32 summation order of the contractions upstream (profiles/r03_bucket_edge_deviation.md).
 // `mean` / `rstd` (the fp32 moments of the shared LayerNorm path) are not used here.
+// value part: pred[m] (returned too); `mean` / `rstd` of the shared fp32 LayerNorm path are not used
 template <int NV>
-__device__ __forceinline__ void predictor_row_tail(const f32x4 (&v)[NV], int C, int lane, float /*mean*/, float /*rstd*/, const RowEpilogue& e,
-                                                   int m, int t, bool masked) {
+__device__ __forceinline__ float predictor_row_value(const f32x4 (&v)[NV], int C, int lane, const RowEpilogue& e, int m, bool masked) {
   double s1 = 0.0;
 #pragma unroll
   for (int i = 0; i < NV; ++i) s1 += ((double)v[i][0] + (double)v[i][1]) + ((double)v[i][2] + (double)v[i][3]);
@@ -122,6 +156,13 @@ __device__ __forceinline__ void predictor_row_tail(const f32x4 (&v)[NV], int C, 
   // unscaled; without one prediction = prediction * control and the embedding comes from the scaled prediction
   if (e.target == nullptr) pv *= e.control;
   if (lane == 0) e.pred[m] = pv;
+  return pv;
+}
+
+template <int NV>
+__device__ __forceinline__ void predictor_row_tail(const f32x4 (&v)[NV], int C, int lane, float /*mean*/, float /*rstd*/, const RowEpilogue& e,
+                                                   int m, int t, bool masked) {
+  const float pv = predictor_row_value<NV>(v, C, lane, e, m, masked);
   if (e.emb == nullptr) return;
   const int cnt = wave_bucketize(e.bins, e.n_edges, e.target ? e.target[m] : pv, lane);
   const float* er = e.emb + (size_t)cnt * e.D;
@@ -131,6 +172,92 @@ __device__ __forceinline__ void predictor_row_tail(const f32x4 (&v)[NV], int C, 
     a += e4;
     if (e.pos) a += *reinterpret_cast<const f32x4*>(e.pos + (size_t)t * e.D + c);
     *reinterpret_cast<f32x4*>(e.x_out + (size_t)m * e.D + c) = a;
+  }
+}
+
+// R rows of one wave at a time (rows m_first, m_first + m_step, ...), for the ticketed GEMM epilogue where one wave owns several
+// rows.  Every load of a stage is issued before the stage's first store and nothing is loaded conditionally: row by row the
+// compiler keeps row j+1's loads behind row j's stores (the output may alias the input for all it knows) and behind row j's
+// mask lookup — R serialized memory round trips (measured: 2200 cycles per row; tools/lab/README.md).
+// The raw rows were published by OTHER workgroups with write-through stores: they are read with sc1 loads through a buffer
+// descriptor (`rs`, over raw [M, ldraw]), which see them wherever they were written — no cache invalidate needed.
+// Same per-row arithmetic as the row-at-a-time kernels (the functions above): bit-identical results.
+// C == NV * 256 exactly (the caller checks); epi: EPI_LN or EPI_LN_PRED.
+typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
+template <int NV, int R>
+__device__ __forceinline__ void row_epilogue_batch(__amdgpu_buffer_rsrc_t rs, int ldraw, int lane, int epi, const RowEpilogue& e, int M, int S,
+                                                   int m_first, int m_step) {
+  constexpr int C = NV * 256;
+  f32x4 v[R][NV];
+  int tt[R], bb_[R];
+  long long ln[R];
+  f32x4 lng[NV], lnb[NV];  // LayerNorm affine of this lane's columns: requested with the rows, not after the moments
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    lng[i] = *reinterpret_cast<const f32x4*>(e.ln_g + lane * 4 + i * 256);
+    lnb[i] = *reinterpret_cast<const f32x4*>(e.ln_b + lane * 4 + i * 256);
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {  // the row loads first, all of them in flight (rows past M read row M-1 and are simply not stored)
+    const int m = m_first + j * m_step, mc = m < M ? m : M - 1;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      v[j][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (mc * ldraw + lane * 4 + i * 256) * 4, 0, 16 /* sc1 */));
+    bb_[j] = mc / S;
+    tt[j] = mc - bb_[j] * S;
+  }
+  if (e.lens) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) ln[j] = e.lens[bb_[j]];
+  } else {
+#pragma unroll
+    for (int j = 0; j < R; ++j) ln[j] = 0x7fffffffffffffffll;
+  }
+  if (epi == EPI_LN) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      float mean, rstd;
+      ln_moments<NV>(v[j], C, lane, mean, rstd);
+      const bool masked = (long long)tt[j] >= ln[j];  // masked_fill(mask, 0)
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[j][i][k] = masked ? 0.f : (v[j][i][k] - mean) * rstd * lng[i][k] + lnb[i][k];  // == ln_store's expression
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int m = m_first + j * m_step;
+      if (m >= M) continue;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(e.y_out + (size_t)m * C + lane * 4 + i * 256) = v[j][i];
+    }
+    return;
+  }
+  // EPI_LN_PRED: values and bucket indices of all rows, then every embedding / input / position row, then the stores
+  int cnt[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int m = m_first + j * m_step, mc = m < M ? m : M - 1;
+    const float pv = predictor_row_value<NV>(v[j], C, lane, e, mc, (long long)tt[j] >= ln[j]);  // (a row past M rewrites pred[M-1] with the same value)
+    cnt[j] = e.emb ? wave_bucketize(e.bins, e.n_edges, e.target ? e.target[mc] : pv, lane) : 0;
+  }
+  if (e.emb == nullptr) return;
+  for (int c0 = 0; c0 < e.D; c0 += 256) {
+    const int c = c0 + lane * 4;
+    if (c >= e.D) break;
+    f32x4 a[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int m = m_first + j * m_step, mc = m < M ? m : M - 1;
+      a[j] = *reinterpret_cast<const f32x4*>(e.x_in + (size_t)mc * e.D + c);
+      a[j] += *reinterpret_cast<const f32x4*>(e.emb + (size_t)cnt[j] * e.D + c);
+      if (e.pos) a[j] += *reinterpret_cast<const f32x4*>(e.pos + (size_t)tt[j] * e.D + c);
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int m = m_first + j * m_step;
+      if (m < M) *reinterpret_cast<f32x4*>(e.x_out + (size_t)m * e.D + c) = a[j];
+    }
   }
 }
 
