@@ -170,6 +170,17 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+  // this lane's bias values (KS == 1 epilogues): requested now, consumed after the K loop (in the epilogue the load's
+  // latency was fully exposed)
+  [[maybe_unused]] float bvp[TN];
+  if constexpr (KS == 1) {
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int n = n0 + wn0 + ni * 32 + (lane & 31);
+      bvp[ni] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
+  }
+
   // fragment read offsets (floats): row (lane&31), slot ((2g + h) ^ f(row)); f is the same for every 32-row tile
   const int frow = lane & 31, fh = lane >> 5;
   int foff[BK / 8];
@@ -295,10 +306,21 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
         if (p.resid && m < p.M) rv[rr][i] = *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + lane * 4 + i * 256);
       }
     }
+    // ... and everything else the row phase reads from memory: the LayerNorm affine of this lane's columns and the mask
+    // lengths of this wave's rows (inside the row loop each was a load -> wait per row)
+    f32x4 lng[NV], lnb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      lng[i] = *reinterpret_cast<const f32x4*>(p.e.ln_g + lane * 4 + i * 256);
+      lnb[i] = *reinterpret_cast<const f32x4*>(p.e.ln_b + lane * 4 + i * 256);
+    }
+    int tt[RPW];
+    bool masked[RPW];
+    row_batch_masks<RPW>(p.e, p.M, p.S, m0 + wid * RPW, 1, tt, masked);
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
       const int nl = wn0 + ni * 32 + ecol;
-      const float bv = p.bias ? p.bias[n0 + nl] : 0.f;
+      const float bv = bvp[ni];
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
@@ -312,36 +334,24 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
       }
     }
     __syncthreads();
+    f32x4 v[RPW][NV];
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int ml = wid * RPW + rr, m = m0 + ml;
-      if (m < p.M) {
-        const int b = m / p.S, t = m - b * p.S;
-        const bool masked = p.e.lens && (long long)t >= p.e.lens[b];
-        if (p.epi == EPI_LN && masked) {  // masked_fill(mask, 0): a padded row is written, never computed
+    for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-          for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(p.Y + (size_t)m * p.ldy + lane * 4 + i * 256) = f32x4{0.f, 0.f, 0.f, 0.f};
-        } else {
-          f32x4 v[NV];
-#pragma unroll
-          for (int i = 0; i < NV; ++i) {
-            v[i] = *reinterpret_cast<const f32x4*>(trow(ml) + lane * 4 + i * 256);
-            if (p.resid) v[i] += rv[rr][i];
-          }
-          float mean, rstd;
-          ln_moments<NV>(v, BN, lane, mean, rstd);
-          if (p.epi == EPI_LN) ln_store<NV>(v, BN, lane, mean, rstd, p.e.ln_g, p.e.ln_b, p.Y + (size_t)m * p.ldy);
-          else predictor_row_tail<NV>(v, BN, lane, mean, rstd, p.e, m, t, masked);
-        }
+      for (int i = 0; i < NV; ++i) {
+        v[rr][i] = *reinterpret_cast<const f32x4*>(trow(wid * RPW + rr) + lane * 4 + i * 256);
+        if (p.resid) v[rr][i] += rv[rr][i];
       }
-    }
+    RowEpilogue e2 = p.e;
+    e2.y_out = p.Y;  // (ldy == BN: checked by the launcher)
+    row_batch_finish<NV, RPW>(v, tt, masked, lane, p.epi, e2, p.M, m0 + wid * RPW, 1, lng, lnb);
   } else {
     if constexpr (KS == 1) {
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
       const int n = n0 + wn0 + ni * 32 + ecol;
       if (n >= p.N) continue;
-      const float bv = p.bias ? p.bias[n] : 0.f;
+      const float bv = bvp[ni];
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
         // the tile's 16 residual values first, all loads in flight together: interleaved with the stores (Y may alias
@@ -428,7 +438,7 @@ hipError_t launch_conv_gemm(const ConvGemm& p_in, hipStream_t st) {
   }
   if (p.epi != EPI_NONE) {
     // full-row tile: 32 rows x N columns, N / 32 waves side by side with one 32x32 MFMA tile each
-    if (!conv_gemm_row_epilogue_ok(p.M, p.N, p.Cin) || (p.ldy & 3) || (p.resid && (p.ldr & 3))) return hipErrorInvalidValue;
+    if (!conv_gemm_row_epilogue_ok(p.M, p.N, p.Cin) || (p.epi == EPI_LN && p.ldy != p.N) || (p.resid && (p.ldr & 3))) return hipErrorInvalidValue;
     if (p.N == 256) return launch_t<32, 256, 32, 1, 1, 8, true>(p, st);
     return launch_t<32, 512, 32, 1, 1, 16, true>(p, st);
   }

@@ -120,7 +120,7 @@ __device__ __forceinline__ void ln_store(const f32x4 (&v)[NV], int C, int lane, 
 // `mean` / `rstd` (the fp32 moments of the shared LayerNorm path) are not used here.
 // value part: pred[m] (returned too); `mean` / `rstd` of the shared fp32 LayerNorm path are not used
 template <int NV>
-__device__ __forceinline__ float predictor_row_value(const f32x4 (&v)[NV], int C, int lane, const RowEpilogue& e, int m, bool masked) {
+__device__ __forceinline__ float predictor_row_value(const f32x4 (&v)[NV], int C, int lane, const RowEpilogue& e, int m, bool masked, bool store = true) {
   double s1 = 0.0;
 #pragma unroll
   for (int i = 0; i < NV; ++i) s1 += ((double)v[i][0] + (double)v[i][1]) + ((double)v[i][2] + (double)v[i][3]);
@@ -155,7 +155,7 @@ __device__ __forceinline__ float predictor_row_value(const f32x4 (&v)[NV], int C
   // model/modules.py:82-89: with a target the embedding comes from bucketize(target) and the prediction is returned
   // unscaled; without one prediction = prediction * control and the embedding comes from the scaled prediction
   if (e.target == nullptr) pv *= e.control;
-  if (lane == 0) e.pred[m] = pv;
+  if (lane == 0 && store) e.pred[m] = pv;
   return pv;
 }
 
@@ -184,45 +184,22 @@ __device__ __forceinline__ void predictor_row_tail(const f32x4 (&v)[NV], int C, 
 // Same per-row arithmetic as the row-at-a-time kernels (the functions above): bit-identical results.
 // C == NV * 256 exactly (the caller checks); epi: EPI_LN or EPI_LN_PRED.
 typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
+
+// second half of a batched row epilogue: R rows already in registers (v[j] = act(contraction + bias) + resid of row
+// m_first + j * m_step; masked[j] / tt[j] = its mask bit and position), LayerNorm affine of this lane's columns in lng / lnb
 template <int NV, int R>
-__device__ __forceinline__ void row_epilogue_batch(__amdgpu_buffer_rsrc_t rs, int ldraw, int lane, int epi, const RowEpilogue& e, int M, int S,
-                                                   int m_first, int m_step) {
+__device__ __forceinline__ void row_batch_finish(f32x4 (&v)[R][NV], const int (&tt)[R], const bool (&masked)[R], int lane, int epi, const RowEpilogue& e,
+                                                 int M, int m_first, int m_step, const f32x4 (&lng)[NV], const f32x4 (&lnb)[NV]) {
   constexpr int C = NV * 256;
-  f32x4 v[R][NV];
-  int tt[R], bb_[R];
-  long long ln[R];
-  f32x4 lng[NV], lnb[NV];  // LayerNorm affine of this lane's columns: requested with the rows, not after the moments
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    lng[i] = *reinterpret_cast<const f32x4*>(e.ln_g + lane * 4 + i * 256);
-    lnb[i] = *reinterpret_cast<const f32x4*>(e.ln_b + lane * 4 + i * 256);
-  }
-#pragma unroll
-  for (int j = 0; j < R; ++j) {  // the row loads first, all of them in flight (rows past M read row M-1 and are simply not stored)
-    const int m = m_first + j * m_step, mc = m < M ? m : M - 1;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-      v[j][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (mc * ldraw + lane * 4 + i * 256) * 4, 0, 16 /* sc1 */));
-    bb_[j] = mc / S;
-    tt[j] = mc - bb_[j] * S;
-  }
-  if (e.lens) {
-#pragma unroll
-    for (int j = 0; j < R; ++j) ln[j] = e.lens[bb_[j]];
-  } else {
-#pragma unroll
-    for (int j = 0; j < R; ++j) ln[j] = 0x7fffffffffffffffll;
-  }
   if (epi == EPI_LN) {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       float mean, rstd;
       ln_moments<NV>(v[j], C, lane, mean, rstd);
-      const bool masked = (long long)tt[j] >= ln[j];  // masked_fill(mask, 0)
 #pragma unroll
       for (int i = 0; i < NV; ++i)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[j][i][k] = masked ? 0.f : (v[j][i][k] - mean) * rstd * lng[i][k] + lnb[i][k];  // == ln_store's expression
+        for (int k = 0; k < 4; ++k) v[j][i][k] = masked[j] ? 0.f : (v[j][i][k] - mean) * rstd * lng[i][k] + lnb[i][k];  // == ln_store's expression; masked_fill(mask, 0)
     }
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -238,7 +215,7 @@ __device__ __forceinline__ void row_epilogue_batch(__amdgpu_buffer_rsrc_t rs, in
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int m = m_first + j * m_step, mc = m < M ? m : M - 1;
-    const float pv = predictor_row_value<NV>(v[j], C, lane, e, mc, (long long)tt[j] >= ln[j]);  // (a row past M rewrites pred[M-1] with the same value)
+    const float pv = predictor_row_value<NV>(v[j], C, lane, e, mc, masked[j], m < M);  // (a row past M computes on whatever its registers hold and stores nothing)
     cnt[j] = e.emb ? wave_bucketize(e.bins, e.n_edges, e.target ? e.target[mc] : pv, lane) : 0;
   }
   if (e.emb == nullptr) return;
@@ -259,6 +236,52 @@ __device__ __forceinline__ void row_epilogue_batch(__amdgpu_buffer_rsrc_t rs, in
       if (m < M) *reinterpret_cast<f32x4*>(e.x_out + (size_t)m * e.D + c) = a[j];
     }
   }
+}
+
+// positions and mask bits of R rows (rows past M take row M-1's): the lens loads of all rows issued together
+template <int R>
+__device__ __forceinline__ void row_batch_masks(const RowEpilogue& e, int M, int S, int m_first, int m_step, int (&tt)[R], bool (&masked)[R]) {
+  int bb_[R];
+  long long ln[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int m = m_first + j * m_step, mc = m < M ? m : M - 1;
+    bb_[j] = mc / S;
+    tt[j] = mc - bb_[j] * S;
+  }
+  if (e.lens) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) ln[j] = e.lens[bb_[j]];
+  } else {
+#pragma unroll
+    for (int j = 0; j < R; ++j) ln[j] = 0x7fffffffffffffffll;
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) masked[j] = (long long)tt[j] >= ln[j];
+}
+
+// ticketed form: the rows come from memory (`rs`: descriptor over raw [M, ldraw]) through sc1 loads, see above
+template <int NV, int R>
+__device__ __forceinline__ void row_epilogue_batch(__amdgpu_buffer_rsrc_t rs, int ldraw, int lane, int epi, const RowEpilogue& e, int M, int S,
+                                                   int m_first, int m_step) {
+  f32x4 v[R][NV];
+  f32x4 lng[NV], lnb[NV];  // LayerNorm affine of this lane's columns: requested with the rows, not after the moments
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    lng[i] = *reinterpret_cast<const f32x4*>(e.ln_g + lane * 4 + i * 256);
+    lnb[i] = *reinterpret_cast<const f32x4*>(e.ln_b + lane * 4 + i * 256);
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {  // the row loads first, all of them in flight (rows past M read row M-1 and are simply not stored)
+    const int m = m_first + j * m_step, mc = m < M ? m : M - 1;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      v[j][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (mc * ldraw + lane * 4 + i * 256) * 4, 0, 16 /* sc1 */));
+  }
+  int tt[R];
+  bool masked[R];
+  row_batch_masks<R>(e, M, S, m_first, m_step, tt, masked);
+  row_batch_finish<NV, R>(v, tt, masked, lane, epi, e, M, m_first, m_step, lng, lnb);
 }
 
 }  // namespace ns
