@@ -258,6 +258,10 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "k_conv_gemm (FFN w_1: Conv1d k=9, d->d_inner, bias+ReLU)",
                      "achieved": round(achieved_tflops, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved_tflops / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                     # algorithmic bytes of one launch: activation rows read once, the weight matrix once, the output written once
+                     "algorithmic_bytes": (geom["rows"] * geom["d_model"] + geom["d_inner"] * geom["k"] * geom["d_model"] + geom["rows"] * geom["d_inner"]) * 4,
+                     "traffic_over_algorithmic": None if traffic is None else round(
+                         traffic / ((geom["rows"] * geom["d_model"] + geom["d_inner"] * geom["k"] * geom["d_model"] + geom["rows"] * geom["d_inner"]) * 4), 3),
                      "frac_of_measured_peak": round(achieved_tflops / F32_MFMA_MEASURED_TFLOPS, 4),
                      "launches": int(k_launches), "avg_launch_ms": round(k_ms / max(k_launches, 1), 4),
                      "share_of_step_time": round((k_ms * 1e-3) / elapsed if elapsed > 0 else 0.0, 3),
@@ -322,6 +326,23 @@ def main():
                         lat.append((time.perf_counter() - t0) * 1e3)
             res["latency"] = {"workload": "cfg1_single: B=1, phoneme_len 100", "p50_ms": round(float(np.median(lat)), 3),
                               "min_ms": round(min(lat), 3), "max_ms": round(max(lat), 3), "mel_len": int(o1[9][0]), "n": len(lat)}
+            # the same utterance in CAPACITY MODE (forward(max_mel_len=<int>), model/modules.py:128-131 `max_len` semantics): the
+            # caller fixes the mel axis, so nothing on the host waits for mel_lens between the two phases.  Capacity = the
+            # utterance's own length here, so the device work is identical to the run above (and so are the outputs, bit for bit).
+            cap = int(o1[9][0])
+            latc = []
+            with torch.no_grad():
+                for i in range(25):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    oc = model(a1[0], a1[1], a1[2], L1, max_mel_len=cap)
+                    torch.cuda.synchronize()
+                    if i >= 5:
+                        latc.append((time.perf_counter() - t0) * 1e3)
+            res["latency_capacity_mode"] = {"workload": f"cfg1_single with max_mel_len={cap} (no host read between the phases)",
+                                            "p50_ms": round(float(np.median(latc)), 3), "min_ms": round(min(latc), 3),
+                                            "max_ms": round(max(latc), 3), "n": len(latc), "status": model.check_status(),
+                                            "bit_identical_to_sync_path": bool(torch.equal(oc[1], o1[1]) and torch.equal(oc[9], o1[9]))}
 
     if args.gpus == 1 and not args.no_cpu_baseline and not args.no_extras:
         # CPU baseline beside it: the oracle (a torch-CPU restatement of the reference forward, "port") on this box's
@@ -376,6 +397,10 @@ def main():
             chk["bucket_flips_off_edge"] = fp[1] + fe[1]
             chk["bucket_flips_by_more_than_one"] = fp[2] + fe[2]
             chk["edge_rel_bound"] = parity.EDGE_REL
+            # the implementation's own distance to the reference on every frame where a decision can change (the bound above is
+            # 2x the worst value of this quantity over the five pins, profiles/r03_bucket_edge_deviation.md)
+            chk["pitch_max_rel_dev_in_range"] = parity.max_rel_deviation(out[2].cpu().numpy(), ref[2].numpy(), pbins, valid)
+            chk["energy_max_rel_dev_in_range"] = parity.max_rel_deviation(pin_p[3].cpu().numpy(), ref[3].numpy(), ebins, valid)
             chk["pitch_max_abs"] = float((out[2].cpu() - ref[2]).abs().max())
             chk["postnet_max_abs_buckets_pinned"] = float((pin[1].cpu() - ref[1]).abs().max())
             chk["frames_over_1e-3_buckets_pinned"] = int((((pin[1].cpu() - ref[1]).abs().amax(dim=2) > 1e-3).numpy() & valid).sum())

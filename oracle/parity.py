@@ -14,11 +14,33 @@ from __future__ import annotations
 
 import numpy as np
 
-# Bound on the reference value's relative distance to a bin edge below which a flipped decision is fp32 summation noise.
-# Typical |HIP - reference| on pitch / energy is 2-4e-6 relative; the largest seen across the five BASELINE pins and kernel
-# revisions is 1.2e-5 (one energy frame of the config-3 shard after the encoder's attention changed its summation order), so
-# the bound sits just above it.  (tests/golden/make_golden.py picks the small fixtures with NO value within 1e-5 of an edge.)
-EDGE_REL = 2e-5
+# Bound on |implementation - reference| / max(|reference|, 1) for pitch / energy values inside the bin range — and therefore
+# on how far from a bin edge (in the same normalisation) a reference value can sit while the two sides still take different
+# buckets.  It is set from a RECORDED distribution, not from one observed maximum: tools/bucket_edge_deviation.py measures the
+# deviation of the HIP path on every in-range frame of the five BASELINE pins (profiles/r03_bucket_edge_deviation.md: 48 000
+# frames each for pitch and energy; median 7e-7 / 1.1e-6, p99.9 1.4e-5 / 1.9e-5, worst 2.28e-5 / 2.12e-5) and the bound is
+# 2x the worst value, rounded.  Round 2's 2e-5 sat BELOW the implementation's own worst case (its flips all happened to lie
+# closer to an edge than that).  The tests assert the deviation itself on every in-range frame (max_rel_deviation below), not
+# only the position of the frames that flipped.  Evaluating the predictors' LayerNorm + Linear tail in float64 does not
+# move these figures (2.27e-5 / 2.11e-5): the deviation is the fp32 summation order of the contractions upstream.
+EDGE_REL = 5e-5
+
+
+def in_range(ref: np.ndarray, bins: np.ndarray, valid: np.ndarray) -> np.ndarray:
+    """Frames where a bucket decision can change at all: valid, and the reference value inside the bin range (1 % margin)."""
+    b = np.asarray(bins, dtype=np.float64)
+    r = np.asarray(ref, dtype=np.float64)
+    lo, hi = b[0] - 0.01 * max(abs(b[0]), 1.0), b[-1] + 0.01 * max(abs(b[-1]), 1.0)
+    return valid & (r >= lo) & (r <= hi)
+
+
+def max_rel_deviation(got: np.ndarray, ref: np.ndarray, bins: np.ndarray, valid: np.ndarray) -> float:
+    """max over the in-range frames of |got - ref| / max(|ref|, 1); 0.0 when there is no such frame."""
+    sel = in_range(ref, bins, valid)
+    if not sel.any():
+        return 0.0
+    g, r = np.asarray(got, dtype=np.float64)[sel], np.asarray(ref, dtype=np.float64)[sel]
+    return float((np.abs(g - r) / np.maximum(np.abs(r), 1.0)).max())
 
 
 def edge_distance(values: np.ndarray, bins: np.ndarray) -> np.ndarray:

@@ -37,25 +37,6 @@ __device__ __forceinline__ int wave_sum(int v) {
   return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 32);
 }
 
-__device__ __forceinline__ double join_d(unsigned lo, unsigned hi) { return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo); }
-template <int CTRL>
-__device__ __forceinline__ double dpp_d(double v) {
-  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-  return join_d((unsigned)dpp_i<CTRL>((int)(unsigned)b), (unsigned)dpp_i<CTRL>((int)(unsigned)(b >> 32)));
-}
-__device__ __forceinline__ double wave_sum(double v) {
-  v += dpp_d<DPP_XOR1>(v);
-  v += dpp_d<DPP_XOR2>(v);
-  v += dpp_d<DPP_HALF_MIRROR>(v);
-  v += dpp_d<DPP_MIRROR>(v);
-  unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-  v += join_d((unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)b, SWZ_XOR16), (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)(b >> 32), SWZ_XOR16));
-  b = __builtin_bit_cast(unsigned long long, v);
-  const int lo = (int)(unsigned)b, hi = (int)(unsigned)(b >> 32);
-  return join_d((unsigned)__builtin_amdgcn_readlane(lo, 0), (unsigned)__builtin_amdgcn_readlane(hi, 0)) +
-         join_d((unsigned)__builtin_amdgcn_readlane(lo, 32), (unsigned)__builtin_amdgcn_readlane(hi, 32));
-}
-
 constexpr float LN_EPS = 1e-5f;  // torch.nn.LayerNorm default
 
 // torch.bucketize(v, bins, right=False) (model/modules.py:86-88,97-99), wave-cooperative: the index is the number
@@ -113,32 +94,16 @@ __device__ __forceinline__ void ln_store(const f32x4 (&v)[NV], int C, int lane, 
 // VarianceAdaptor.forward (model/modules.py:80-100,139-149):
 //   idx = bucketize(pred*control, bins)  (right=False; NaN -> n_bins-1)
 //   x_out[m,:] = x_in[m,:] + emb[idx,:]  (+ pos[t,:]: MelDecoder's position add, transformer/Models.py:222,231)
-// The row feeds a DISCONTINUOUS consumer (duration rounding, torch.bucketize): layer_norm_2 and the Linear(F->1) dot are
-// therefore evaluated in float64 from the fp32 row (mean, centred variance, normalisation, dot: ~1k flops per row, free next
-// to the convolution that produced it), so that this tail adds no rounding of its own to the distance from the reference's
-// value — what remains is the fp32 summation order of the contractions upstream (profiles/r03_bucket_edge_deviation.md).
-// `mean` / `rstd` (the fp32 moments of the shared LayerNorm path) are not used here.
-// value part: pred[m] (returned too); `mean` / `rstd` of the shared fp32 LayerNorm path are not used
+// (Round 3 evaluated layer_norm_2 + Linear(F->1) in float64 to shrink the distance to the reference's value ahead of the
+// discontinuous consumers — duration rounding, torch.bucketize.  Measured on the five pins: worst relative deviation 2.27e-5 /
+// 2.11e-5 (pitch / energy) with the float64 tail against 2.28e-5 / 2.12e-5 with this fp32 one — the deviation is set by the
+// fp32 summation order of the contractions upstream, not by these 256-term sums.  profiles/r03_bucket_edge_deviation.md.)
+// value part: pred[m] (returned too)
 template <int NV>
 __device__ __forceinline__ float predictor_row_value(const f32x4 (&v)[NV], int C, int lane, const RowEpilogue& e, int m, bool masked, bool store = true) {
-  double s1 = 0.0;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) s1 += ((double)v[i][0] + (double)v[i][1]) + ((double)v[i][2] + (double)v[i][3]);
-  const double mu = wave_sum(s1) / (double)C;
-  double s2 = 0.0;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = lane * 4 + i * 256;
-    if (c < C) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const double dl = (double)v[i][k] - mu;
-        s2 += dl * dl;
-      }
-    }
-  }
-  const double rs = 1.0 / sqrt(wave_sum(s2) / (double)C + (double)LN_EPS);
-  double dot = 0.0;
+  float mean, rstd;
+  ln_moments<NV>(v, C, lane, mean, rstd);
+  float dot = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + i * 256;
@@ -147,10 +112,10 @@ __device__ __forceinline__ float predictor_row_value(const f32x4 (&v)[NV], int C
       const f32x4 bb = *reinterpret_cast<const f32x4*>(e.ln_b + c);
       const f32x4 ww = *reinterpret_cast<const f32x4*>(e.wlin + c);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) dot += (((double)v[i][k] - mu) * rs * (double)gg[k] + (double)bb[k]) * (double)ww[k];
+      for (int k = 0; k < 4; ++k) dot += ((v[i][k] - mean) * rstd * gg[k] + bb[k]) * ww[k];
     }
   }
-  float pv = (float)(wave_sum(dot) + (double)e.blin[0]);
+  float pv = wave_sum(dot) + e.blin[0];
   if (masked) pv = 0.f;
   // model/modules.py:82-89: with a target the embedding comes from bucketize(target) and the prediction is returned
   // unscaled; without one prediction = prediction * control and the embedding comes from the scaled prediction

@@ -43,6 +43,14 @@ def test_bench_json_contract():
     rec = json.load(open(os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")))
     same = all(rec.get(k) == v for k, v in ro["geometry"].items())
     assert (ro["traffic"] == rec["hbm_bytes_per_launch"]) if same else (ro["traffic"] is None)
+    assert ro["algorithmic_bytes"] == (ro["geometry"]["rows"] * 256 + 1024 * 9 * 256 + ro["geometry"]["rows"] * 1024) * 4
+    assert (ro["traffic_over_algorithmic"] is None) == (ro["traffic"] is None)
+    if ro["traffic"] is not None:
+        assert abs(ro["traffic_over_algorithmic"] - ro["traffic"] / ro["algorithmic_bytes"]) < 1e-3
+    # both latency figures of config 1: the synchronous forward (the headline p50) and capacity mode beside it
+    lat, cap = d["latency"], d["latency_capacity_mode"]
+    assert lat["p50_ms"] > 0 and cap["p50_ms"] > 0 and cap["bit_identical_to_sync_path"] is True and cap["status"] == [0]
+    assert [x["rank"] for x in d["per_rank"]] == [0] and d["per_rank"][0]["valid_frames"] == d["config"]["valid_frames_per_step"]
     rb = d["roofline_by_kernel"]
     assert set(rb) == {"ffn_w1", "attention", "postnet_mid"}
     assert rb["attention"]["launches"] == 3 * 4 and rb["postnet_mid"]["launches"] == 3 * 3

@@ -47,7 +47,7 @@ def run_gpu(m, z, meta, texts_key="texts", p_targets=None, e_targets=None):
     return out
 
 
-from oracle.parity import EDGE_REL  # noqa: E402  relative distance to a bucket edge below which a flip is fp32 noise (2e-5)
+from oracle.parity import EDGE_REL  # noqa: E402  relative distance to a bucket edge below which a flip is fp32 noise (oracle/parity.py)
 
 
 def bucket_flips(sd, out, z, which="pe", what="free run"):
@@ -176,9 +176,15 @@ def test_position_table_switch(name):
     assert np.array_equal(out[9].cpu().numpy(), z["mel_lens"])
     assert np.array_equal(out[5].cpu().numpy(), z["d_rounded"])
     close(out[2], z["p_predictions"], 2e-3, "pitch")
+    from oracle import parity
+    valid = ~z["mel_masks"]
+    dp = parity.max_rel_deviation(out[2].cpu().numpy(), z["p_predictions"], sd["variance_adaptor.pitch_bins"], valid)
+    assert dp <= EDGE_REL, ("pitch deviates from the reference by more than the recorded noise bound", dp)
     n_flip = bucket_flips(sd, out, z, "p")
     tf = run_gpu(m, z, meta, p_targets=z["p_predictions"], e_targets=z["e_predictions"])
     close(tf[3], z["e_predictions"], MEL_TOL, "energy")
+    de = parity.max_rel_deviation(tf[3].cpu().numpy(), z["e_predictions"], sd["variance_adaptor.energy_bins"], valid)
+    assert de <= EDGE_REL, ("energy deviates from the reference by more than the recorded noise bound", de)
     n_flip += bucket_flips(sd, tf, z, "e", "pitch-pinned run")
     e = close(tf[1], z["postnet_output"], MEL_TOL, "postnet mel")
     print(name, "T", out[0].shape[1], "edge bucket flips", n_flip, "postnet err", e)
@@ -273,19 +279,25 @@ def test_baseline_configs_vs_reference_pins(name):
     assert np.array_equal(out[9].cpu().numpy(), z["mel_lens"])
     assert np.array_equal(out[7].cpu().numpy(), z["mel_masks"])
     close(out[2], z["p_predictions"], 2e-3, "pitch")
+    from oracle import parity
+    valid = ~z["mel_masks"]
+    dp = parity.max_rel_deviation(out[2].cpu().numpy(), z["p_predictions"], sd["variance_adaptor.pitch_bins"], valid)
+    assert dp <= EDGE_REL, ("pitch deviates from the reference by more than the recorded noise bound", dp)
     n_flip = bucket_flips(sd, out, z, "p")
     st = meta["frame_stride"]
     # the energy predictor reads x + pitch_embedding: compare it (and everything downstream) with the pitch buckets
     # pinned to the reference's; an edge flip of a pitch bucket legitimately moves energy at the 5 frames around it
     tf = run_gpu(m, z, meta, p_targets=z["p_predictions"], e_targets=z["e_predictions"])
     close(tf[3], z["e_predictions"], MEL_TOL, "energy")
+    de = parity.max_rel_deviation(tf[3].cpu().numpy(), z["e_predictions"], sd["variance_adaptor.energy_bins"], valid)
+    assert de <= EDGE_REL, ("energy deviates from the reference by more than the recorded noise bound", de)
     n_flip += bucket_flips(sd, tf, z, "e", "pitch-pinned run")
     if n_flip == 0:
         close(out[0][:, ::st], z["output_sub"], MEL_TOL, "mel (free run)")
     e1 = close(tf[0][:, ::st], z["output_sub"], MEL_TOL, "mel")
     e2 = close(tf[1][:, ::st], z["postnet_output_sub"], MEL_TOL, "postnet mel")
     print(name, "B", int(meta["B"]), "L", int(meta["L"]), "T", out[0].shape[1], "frames", int(z["mel_lens"].sum()),
-          "edge bucket flips in free run", n_flip,
+          "edge bucket flips in free run", n_flip, "max in-range relative deviation pitch / energy", dp, de,
           "mel err", e1, "postnet err", e2)
 
 
@@ -355,6 +367,8 @@ def _pinned_vs_oracle(m, w, cfg, inp, ref, what, **kw):
     valid = ~ref[7].numpy()
     fp = parity.classify_bucket_flips(out[2].cpu().numpy(), ref[2].numpy(), w["variance_adaptor.pitch_bins"].numpy(), valid)
     assert fp[1] == 0 and fp[2] == 0, (what, "pitch bucket flips away from a bin edge / by more than one", fp)
+    dp = parity.max_rel_deviation(out[2].cpu().numpy(), ref[2].numpy(), w["variance_adaptor.pitch_bins"].numpy(), valid)
+    assert dp <= parity.EDGE_REL, (what, "pitch deviates from the oracle by more than the recorded noise bound", dp)
     pc, ec = kw.get("p_control", 1.0), kw.get("e_control", 1.0)
     with torch.no_grad():
         # the oracle's free-run predictions are already scaled by p/e_control; as targets they are bucketized as is
@@ -362,7 +376,9 @@ def _pinned_vs_oracle(m, w, cfg, inp, ref, what, **kw):
         pp = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3], p_targets=ref[2].cuda(), e_control=ec)
     fe = parity.classify_bucket_flips(pp[3].cpu().numpy(), ref[3].numpy(), w["variance_adaptor.energy_bins"].numpy(), valid)
     assert fe[1] == 0 and fe[2] == 0, (what, "energy bucket flips away from a bin edge / by more than one", fe)
-    return {"edge_flips": fp[0] + fe[0], "energy": close(tf[3] * ec, ref[3].numpy(), MEL_TOL, what + " energy"),
+    de = parity.max_rel_deviation(pp[3].cpu().numpy(), ref[3].numpy(), w["variance_adaptor.energy_bins"].numpy(), valid)
+    assert de <= parity.EDGE_REL, (what, "energy deviates from the oracle by more than the recorded noise bound", de)
+    return {"edge_flips": fp[0] + fe[0], "max_rel_dev": max(dp, de), "energy": close(tf[3] * ec, ref[3].numpy(), MEL_TOL, what + " energy"),
             "mel": close(tf[0], ref[0].numpy(), MEL_TOL, what + " mel"),
             "postnet": close(tf[1], ref[1].numpy(), MEL_TOL, what + " postnet mel"), "out": out}
 

@@ -9,7 +9,7 @@
 # MI355X_MICROARCH.md prescribes).  bench.py runs with --no-extras under the profiler: the trace then holds exactly
 # (warmup + steps) forwards of the workload, nothing else.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
@@ -18,7 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 python "$ROOT/bench.py" > "$OUT/${R}_bench.log" 2>&1
 tail -1 "$OUT/${R}_bench.log" > "$OUT/${R}_bench.json"
 
-for WL in cfg2_b16 cfg1_single cfg4_d512 cfg5_longform; do
+for WL in cfg2_b16 cfg1_single cfg4_d512 cfg5_longform cfg5_longform_gaussian; do
   TAG=${R}_trace; [ "$WL" != cfg2_b16 ] && TAG=${R}_trace_${WL}
   BENCH="python $ROOT/bench.py --workload $WL --steps 5 --warmup 2 --no-extras"
   rocprofv3 --kernel-trace --stats --output-format rocpd csv -d "$OUT/$TAG" -o t -- $BENCH > "$OUT/$TAG.log" 2>&1
@@ -37,6 +37,10 @@ for WL in cfg2_b16 cfg5_longform; do
   rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY \
     -d "$OUT/${R}_lds$SUF" -o t -- $BENCH > "$OUT/${R}_lds$SUF.log" 2>&1
 done
+# single utterance: fabric fetch per launch (are the small-grid GEMMs re-streaming weights? tools/lab/README.md round 3)
+BENCH="python $ROOT/bench.py --workload cfg1_single --steps 5 --warmup 2 --no-extras"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/${R}_fetch_cfg1_single" -o t -- $BENCH > "$OUT/${R}_fetch_cfg1_single.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/${R}_write_cfg1_single" -o t -- $BENCH > "$OUT/${R}_write_cfg1_single.log" 2>&1
 # the opt-in bf16x3 mode, for the record (never the headline)
 python "$ROOT/bench.py" --matmul bf16x3 --no-cpu-baseline > "$OUT/${R}_bench_bf16x3.log" 2>&1
 tail -1 "$OUT/${R}_bench_bf16x3.log" > "$OUT/${R}_bench_bf16x3.json"

@@ -33,26 +33,25 @@ ne, nd = (int(x) for x in re.search(r"(\d+)\+(\d+) FFT layers", cw).groups())
 d_inner, F, n_mel, pdim = 1024, 256, 80, 512
 
 
+# The expected launch sequence (api.hip: ns_forward_durations then ns_forward_mel).  Entries marked optional are separate
+# launches only on some paths (a split-key merge after k_attention; a LayerNorm / predictor-tail row kernel when neither the
+# full-row tile nor the ticketed epilogue applied; the position-table rebuild for S > max_seq_len) and are matched by name.
 def ops(S, layers, tag):
     M = B * S
     out = []
     for i in range(layers):
-        out += [(f"{tag}{i} QKV projection", 2 * M * d * 3 * d), (f"{tag}{i} attention", 4 * M * S * d)]
-        out += [(f"{tag}{i} attention merge", 0)] if MERGE[tag] else []
-        out += [(f"{tag}{i} fc (+resid" + (" +LN)" if FUSED[tag] else ")"), 2 * M * d * d)]
-        out += [] if FUSED[tag] else [(f"{tag}{i} LayerNorm", 0)]
-        out += [(f"{tag}{i} FFN w_1 k=9", 2 * M * 9 * d * d_inner), (f"{tag}{i} FFN w_2 (+resid" + (" +LN)" if FUSED[tag] else ")"), 2 * M * d_inner * d)]
-        out += [] if FUSED[tag] else [(f"{tag}{i} LayerNorm", 0)]
+        out += [(f"{tag}{i} QKV projection", 2 * M * d * 3 * d, None), (f"{tag}{i} attention", 4 * M * S * d, None)]
+        out += [(f"{tag}{i} attention merge", 0, "k_attention_merge")]
+        out += [(f"{tag}{i} fc (+resid +LN)", 2 * M * d * d, None), (f"{tag}{i} LayerNorm", 0, "k_layernorm")]
+        out += [(f"{tag}{i} FFN w_1 k=9", 2 * M * 9 * d * d_inner, None), (f"{tag}{i} FFN w_2 (+resid +LN)", 2 * M * d_inner * d, None)]
+        out += [(f"{tag}{i} LayerNorm", 0, "k_layernorm")]
     return out
 
 
-def predictor(S, tag, fused):
+def predictor(S, tag):
     M = B * S
-    o = [(f"{tag} predictor conv1 k=3" + (" +LN" if fused else ""), 2 * M * 3 * d * F)]
-    o += [] if fused else [(f"{tag} predictor LayerNorm", 0)]
-    o += [(f"{tag} predictor conv2 k=3" + (" +LN+linear+embed" if fused else ""), 2 * M * 3 * F * F)]
-    o += [] if fused else [(f"{tag} predictor LN+linear(+embed)", 0)]
-    return o
+    return [(f"{tag} predictor conv1 k=3 +LN", 2 * M * 3 * d * F, None), (f"{tag} predictor LayerNorm", 0, "k_layernorm"),
+            (f"{tag} predictor conv2 k=3 +LN+linear+embed", 2 * M * 3 * F * F, None), (f"{tag} predictor LN+linear(+embed)", 0, "k_ln_linear_embed")]
 
 
 con = sqlite3.connect(f"{G}/{ROUND}_trace{SUF}/t_results.db")
@@ -60,26 +59,21 @@ rows = con.execute("select name, start, end, grid_x / workgroup_x * (grid_y / wo
 idx = [i for i, r in enumerate(rows) if "k_embed_pos" in r[0]]
 seq = [r for r in rows[idx[-2]:idx[-1]] if "rocclr" not in r[0]]
 names = [r[0] for r in seq]
-MERGE = {"enc": False, "dec": False}
-FUSED = {"enc": (B * L + 31) // 32 >= 200, "dec": (B * T + 31) // 32 >= 200}
-# does this trace contain merge kernels per stack?  (split-key attention is taken for small launches)
-n_merge = sum("k_attention_merge" in n for n in names)
-first_dec = next((i for i, n in enumerate(names) if "k_length_regulate" in n or "k_gauss" in n), len(names))
-MERGE["enc"] = any("k_attention_merge" in n for n in names[:first_dec])
-MERGE["dec"] = any("k_attention_merge" in n for n in names[first_dec:])
+gaussian = any("k_gauss_upsample" in n for n in names)
 
-plan = [("embedding + positions", 0)] + ops(L, ne, "enc") + predictor(L, "duration", FUSED["enc"]) + [("duration round / scan / masks", 0)]
-plan += [("length regulator", 0)] + predictor(T, "pitch", FUSED["dec"]) + predictor(T, "energy", FUSED["dec"])
-if T > 1000:
-    plan.insert(len(plan) - (4 if not FUSED["dec"] else 2) * 2, ("sinusoid table rebuild (T > max_seq_len)", 0))
-plan += ops(T, nd, "dec") + [("mel_linear", 2 * B * T * d * n_mel)]
+full = [("embedding + positions", 0, None), ("sinusoid table rebuild (L > max_seq_len)", 0, "k_sinusoid")] + ops(L, ne, "enc") + predictor(L, "duration")
+full += [("duration round / scan / masks", 0, None)]
+full += ([("Gaussian centres (cumsum)", 0, None), ("Gaussian upsampling w^T x", 2 * B * T * L * d, None)] if gaussian else [("length regulator", 0, None)])
+full += [("sinusoid table rebuild (T > max_seq_len)", 0, "k_sinusoid")] + predictor(T, "pitch") + predictor(T, "energy")
+full += ops(T, nd, "dec") + [("mel_linear", 2 * B * T * d * n_mel, None)]
 chans = [n_mel, pdim, pdim, pdim, pdim, n_mel]
-plan += [(f"PostNet conv {i} k=5 {chans[i]}->{chans[i + 1]}", 2 * B * T * 5 * chans[i] * chans[i + 1]) for i in range(5)]
-
-# the sinusoid kernel's position: find it in the trace and move the plan entry there
-if any("k_sinusoid" in n for n in names):
-    plan = [p for p in plan if not p[0].startswith("sinusoid")]
-    plan.insert(next(i for i, n in enumerate(names) if "k_sinusoid" in n), ("sinusoid table rebuild (T > max_seq_len)", 0))
+full += [(f"PostNet conv {i} k=5 {chans[i]}->{chans[i + 1]}", 2 * B * T * 5 * chans[i] * chans[i + 1], None) for i in range(5)]
+plan, k = [], 0
+for op, fl, opt in full:
+    if opt is not None and not (k < len(names) and opt in names[k]):
+        continue
+    plan.append((op, fl))
+    k += 1
 if len(plan) != len(seq):
     print(f"launch plan ({len(plan)}) does not match the trace ({len(seq)}); kernels:", file=sys.stderr)
     for i in range(max(len(plan), len(seq))):
@@ -121,7 +115,7 @@ for i, ((op, fl), r) in enumerate(zip(plan, seq)):
     us = (r[2] - r[1]) / 1e3
     kn = re.sub(r"\(.*", "", r[0]).replace("void ", "").replace("ns::", "")
     tf = fl / us / 1e6 if fl else 0.0
-    row = f"| {i} | {op} | `{kn[:48]}` | {int(r[3])} | {us:.1f} | {fl / 1e9:.2f} | {tf:.1f} | {tf / PEAK:.2f} | {100 * us / tot_t:.1f} |"
+    row = f"| {i} | {op} | `{kn[:52]}` | {int(r[3])} | {us:.1f} | {fl / 1e9:.2f} | {tf:.1f} | {tf / PEAK:.2f} | {100 * us / tot_t:.1f} |"
     if have_pmc:
         row += f" {(fetch[i] * 2048 + write[i] * 1024) / 1e6:.1f} |"
     lines.append(row)
