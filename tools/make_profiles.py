@@ -66,7 +66,7 @@ if rows:
     per_fwd = max(1, len(durs) // max(1, (under["steps"] + under["warmup"])))
     fwd_avgs = [sum(durs[i:i + per_fwd]) / per_fwd for i in range(0, len(durs) - per_fwd + 1, per_fwd)]
     last = durs[-per_fwd:]
-    frac = lambda us: gflop / us / 1e3 / 157.3 * 1e3
+    frac = lambda us: gflop / us * 1e3 / 157.3  # GFLOP / us = PFLOP/s
     under["dominant_kernel_averages"] = {
         "gflop_per_launch": round(gflop, 2),
         "all_traced_launches": {"n": len(durs), "avg_us": round(sum(durs) / len(durs), 1), "frac": round(frac(sum(durs) / len(durs)), 4)},

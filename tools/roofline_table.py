@@ -63,7 +63,7 @@ gaussian = any("k_gauss_upsample" in n for n in names)
 
 full = [("embedding + positions", 0, None), ("sinusoid table rebuild (L > max_seq_len)", 0, "k_sinusoid")] + ops(L, ne, "enc") + predictor(L, "duration")
 full += [("duration round / scan / masks", 0, None)]
-full += ([("Gaussian centres (cumsum)", 0, None), ("Gaussian upsampling w^T x", 2 * B * T * L * d, None)] if gaussian else [("length regulator", 0, None)])
+full += ([("mel mask", 0, "k_mask"), ("Gaussian centres (cumsum)", 0, None), ("Gaussian upsampling w^T x", 2 * B * T * L * d, None)] if gaussian else [("length regulator", 0, None)])
 full += [("sinusoid table rebuild (T > max_seq_len)", 0, "k_sinusoid")] + predictor(T, "pitch") + predictor(T, "energy")
 full += ops(T, nd, "dec") + [("mel_linear", 2 * B * T * d * n_mel, None)]
 chans = [n_mel, pdim, pdim, pdim, pdim, n_mel]
