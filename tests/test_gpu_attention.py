@@ -38,6 +38,30 @@ def test_attention_vs_float64(H, dk, S, lens):
         assert err < 2e-5, (b, err)
 
 
+@pytest.mark.parametrize("H,dk,S,lens", [(2, 128, 100, [100]), (2, 128, 128, [128, 97, 64, 5] * 4), (2, 128, 788, [788]), (2, 128, 1010, [1010, 700, 33]),
+                                         (8, 64, 300, [300, 257, 129]), (4, 32, 130, [130, 1])])
+def test_attention_vs_oracle_a5(H, dk, S, lens):
+    """Row a5 against the ORACLE's own restatement of ScaledDotProductAttention (oracle/fs2_oracle.py, the function the
+    pinned multi_head_attention goes through; fp32 torch-CPU like the reference), on shapes that take each of the three launch
+    forms: the strip kernel without a cross-workgroup merge (S <= 128), the strip kernel with the last-arriver merge (single
+    utterance, T = 788), and k_attention (config 2's T = 1010).  All S query rows are compared — padded ones are computed by
+    the reference too."""
+    from oracle import fs2_oracle as orc
+    from smart_nar_fast_tts_amd import ops
+
+    torch.manual_seed(S + dk)
+    B, d = len(lens), H * dk
+    qkv = torch.randn(B, S, 3 * d)
+    lens_t = torch.tensor(lens)
+    q, k, v = (qkv[..., i * d:(i + 1) * d].reshape(B, S, H, dk).permute(2, 0, 1, 3).reshape(-1, S, dk) for i in range(3))  # SubLayers.py:42-47
+    key_pad = torch.arange(S)[None, :] >= lens_t[:, None]
+    ref = orc.scaled_dot_product_attention(q, k, v, key_pad.unsqueeze(1).expand(-1, S, -1).repeat(H, 1, 1), dk)
+    ref = ref.view(H, B, S, dk).permute(1, 2, 0, 3).reshape(B, S, d)                                                      # SubLayers.py:52-54
+    got = ops.attention_core(qkv.cuda(), lens_t.cuda(), H).cpu()
+    err = (got - ref).abs().max().item()
+    assert err < 2e-5, err
+
+
 def test_attention_forced_rescale_late_tile():
     """Spike one key per query block far above the rest at a LATE tile so the reference point must move there;
     also a descending spike pattern (first tile largest) so it must NOT move afterwards."""
