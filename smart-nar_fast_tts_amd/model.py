@@ -8,8 +8,11 @@ unchanged.  All tensor math happens in the HIP kernels behind the C-ABI
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import functools
 import json
+import math
 import os
 import time
 from collections import OrderedDict
@@ -49,6 +52,42 @@ def config_struct(preprocess_config: dict, model_config: dict) -> _lib.NsConfig:
     )
 
 
+class _OutputBlock:
+    """Several output tensors cut from ONE device allocation (a torch.empty costs the host 2-4 us, and the forward's host
+    work sits on the latency path of a single utterance): ``ptr(name)`` for the native call, ``view(name)`` for the caller.
+    ``layout`` may be called again with smaller shapes (capacity allocation: sizes known only after the hand-over)."""
+    _ALIGN = 256
+
+    def __init__(self, specs, device):
+        self.layout(specs)
+        self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
+        self.base = self.buf.data_ptr()
+
+    def layout(self, specs):
+        self.at, self.nbytes = _block_layout(tuple(specs))
+
+    def ptr(self, name) -> C.c_void_p:
+        return C.c_void_p(self.base + self.at[name][0]) if name in self.at else C.c_void_p(0)
+
+    def view(self, name) -> torch.Tensor:
+        off, n, shape, dtype = self.at[name]
+        return self.buf[off:off + n].view(dtype).view(shape)
+
+
+_ITEMSIZE = {torch.float32: 4, torch.bool: 1, torch.long: 8, torch.int32: 4}
+
+
+@functools.lru_cache(maxsize=2048)
+def _block_layout(specs):
+    """((name, shape, dtype), ...) -> ({name: (byte offset, bytes, shape, dtype)}, total bytes); 256-byte aligned entries."""
+    off, at = 0, {}
+    for name, shape, dtype in specs:
+        n = math.prod(shape) * _ITEMSIZE[dtype]
+        at[name] = (off, n, shape, dtype)
+        off += (n + _OutputBlock._ALIGN - 1) // _OutputBlock._ALIGN * _OutputBlock._ALIGN
+    return at, max(off, _OutputBlock._ALIGN)
+
+
 class FastSpeech2Align:
     """FastSpeech2 (inference) — HIP/gfx950 implementation of the reference module of the same name."""
 
@@ -63,6 +102,8 @@ class FastSpeech2Align:
         self._device = None
         self._arena = None
         self._ws = OrderedDict()  # (kind, stream handle) -> scratch tensor, least recently used first
+        self._t_hint = {}         # (B, L) -> T of the last synchronous forward of that shape (capacity guess for the next one)
+        self._ws_need = {}        # (kind, B, L, T) -> bytes (ns_*_ws_bytes is a pure function of the config and these)
         self._sd = OrderedDict()  # host copy of what load_state_dict received (for state_dict() / .to())
         self._loaded = False      # a full inference state dict was accepted (load_state_dict) ...
         self._adopted = False     # ... or the packed arena arrived as bytes (adopt_arena)
@@ -249,12 +290,12 @@ class FastSpeech2Align:
     # ---- forward -------------------------------------------------------------------------------
     MAX_WORKSPACE_STREAMS = 4  # scratch sets kept alive (each is an enc + dec pair; config 2: ~230 MB per stream)
 
-    def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
+    def _workspace(self, key: str, nbytes: int, stream_handle=None) -> torch.Tensor:
         # one scratch set per (kind, stream): forwards issued on different streams may run concurrently on the GPU
         # (batching.synthesize pipelines consecutive batches that way) and must not share temporaries.  The cache is
         # LRU-bounded: every synthesize(streams=N) call makes fresh streams, and a dropped set goes back to torch's
         # caching allocator, which only re-issues it in stream order.
-        key = (key, torch.cuda.current_stream(self._device).cuda_stream)
+        key = (key, stream_handle if stream_handle is not None else torch.cuda.current_stream(self._device).cuda_stream)
         w = self._ws.get(key)
         if w is None or w.numel() < nbytes:
             w = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self._device)
@@ -264,16 +305,28 @@ class FastSpeech2Align:
             self._ws.popitem(last=False)
         return w
 
-    def _pinned_lens(self, B: int) -> torch.Tensor:
+    def _pinned_lens(self, B: int, stream_handle=None):
         """[B] int64 in pinned (device-visible) host memory, one buffer per launch stream: phase 1's last kernel writes
-        mel_lens there as well, so the forward's single host read is a stream synchronisation."""
-        key = ("pin", torch.cuda.current_stream(self._device).cuda_stream)
+        mel_lens there as well, so the forward's single host read is a stream synchronisation.  Returns the tensor and a
+        numpy view of the same memory (the host reads max / min through it: no torch dispatch on the hand-over path)."""
+        key = ("pin", stream_handle if stream_handle is not None else torch.cuda.current_stream(self._device).cuda_stream)
         t = self._ws.get(key)
-        if t is None or t.numel() < B:
-            t = torch.empty(max(B, 64), dtype=torch.long, pin_memory=True)
+        if t is None or t[0].numel() < B:
+            buf = torch.empty(max(B, 64), dtype=torch.long, pin_memory=True)
+            t = (buf, buf.numpy())
             self._ws[key] = t
         self._ws.move_to_end(key)
-        return t[:B]
+        return t[0][:B], t[1][:B]
+
+    def _ws_bytes(self, kind: str, B: int, L: int, T: int) -> int:
+        key = (kind, B, L, T)
+        n = self._ws_need.get(key)
+        if n is None:
+            n = (self._lib.ns_encoder_ws_bytes(self._h, B, L) if kind == "enc" else self._lib.ns_decoder_ws_bytes(self._h, B, L, T))
+            if len(self._ws_need) > 4096:
+                self._ws_need.clear()
+            self._ws_need[key] = n
+        return n
 
     def release_workspaces(self):
         """Drop every cached scratch set (they are re-created on demand)."""
@@ -346,37 +399,52 @@ class FastSpeech2Align:
             raise ValueError(f"max_src_len ({int(max_src_len)}) must equal texts.shape[1] ({L})")
         texts_c = texts.long().contiguous()
         lens_c = src_lens.to(device=dev, dtype=torch.long).contiguous()
-        with torch.cuda.device(dev):
-            st = _lib.stream_ptr(dev)
-            f32 = dict(dtype=torch.float32, device=dev)
-            log_d = torch.empty(B, L, **f32)
-            d_rounded = torch.empty(B, L, **f32)
-            src_masks = torch.empty(B, L, dtype=torch.bool, device=dev)
-            out_mel_lens = torch.empty(B, dtype=torch.long, device=dev)
-            ws_enc_bytes = lib.ns_encoder_ws_bytes(self._h, B, L)
-            ws_enc = self._workspace("enc", ws_enc_bytes)
-            # a phoneme_level feature is predicted on the encoder output ([B,L], model/modules.py:117-126),
-            # a frame_level one after the length regulator ([B,T], :139-149)
-            p_frame, e_frame = bool(self._cfg.pitch_frame_level), bool(self._cfg.energy_frame_level)
+        # a phoneme_level feature is predicted on the encoder output ([B,L], model/modules.py:117-126),
+        # a frame_level one after the length regulator ([B,T], :139-149)
+        p_frame, e_frame = bool(self._cfg.pitch_frame_level), bool(self._cfg.energy_frame_level)
+        n_mel = self._cfg.n_mel
+        f32, u8, i64, i32 = torch.float32, torch.bool, torch.long, torch.int32
 
-            def target(name, t, shape):
-                if t is None:
-                    return None
-                if tuple(t.shape) != shape:
-                    raise ValueError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
-                return t.to(device=dev, dtype=torch.float32).contiguous()
+        def target(name, t, shape):
+            if t is None:
+                return None
+            if tuple(t.shape) != shape:
+                raise ValueError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
+            return t.to(device=dev, dtype=torch.float32).contiguous()
 
-            p_pred = None if p_frame else torch.empty(B, L, **f32)
-            e_pred = None if e_frame else torch.empty(B, L, **f32)
-            pin = self._pinned_lens(B)
+        def phase2_outputs(T):
+            o = [("mel", (B, T, n_mel), f32), ("post", (B, T, n_mel), f32), ("mel_masks", (B, T), u8)]
+            if p_frame:
+                o.append(("p_pred", (B, T), f32))
+            if e_frame:
+                o.append(("e_pred", (B, T), f32))
+            return o
+
+        # (the device guard costs the host ~4 us: only taken when the current device is another one)
+        with (contextlib.nullcontext() if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)):
+            sh = torch.cuda.current_stream(dev).cuda_stream
+            st = C.c_void_p(sh)
+            # Host work is ordered around the GPU's critical path: ONE allocation per phase (the views the caller receives are
+            # cut from it after the last launch is enqueued), and everything phase 2 needs that does not depend on T — its
+            # output block and scratch at a capacity guessed from the previous forward of this shape — is prepared while
+            # phase 1 runs, so that between "mel_lens is readable" and phase 2's first launch there is one numpy max and one
+            # ctypes call (tools/host_breakdown.py: 20 us of Python there before, 22 us ahead of the first launch).
+            o1 = [("log_d", (B, L), f32), ("d_rounded", (B, L), f32), ("src_masks", (B, L), u8), ("mel_lens", (B,), i64),
+                  ("status", (B,), i32)]
+            if not p_frame:
+                o1.append(("p_pred", (B, L), f32))
+            if not e_frame:
+                o1.append(("e_pred", (B, L), f32))
+            blk1 = _OutputBlock(o1, dev)
+            ws_enc = self._workspace("enc", self._ws_bytes("enc", B, L, 0), sh)
+            pin, pin_np = self._pinned_lens(B, sh)
             _lib.check(lib.ns_forward_durations(
                 self._h, _lib.ptr(texts_c), _lib.ptr(lens_c), B, L, 1.0, float(p_control), float(e_control),
                 _lib.ptr(None if p_frame else target("p_targets", p_targets, (B, L))),
                 _lib.ptr(None if e_frame else target("e_targets", e_targets, (B, L))),
-                _lib.ptr(ws_enc), ws_enc.numel(), _lib.ptr(log_d), _lib.ptr(d_rounded), _lib.ptr(src_masks),
-                _lib.ptr(out_mel_lens), _lib.ptr(p_pred), _lib.ptr(e_pred), _lib.ptr(pin), st), "ns_forward_durations")
-            status = torch.empty(B, dtype=torch.int32, device=dev)
-            self.last_status = status
+                _lib.ptr(ws_enc), ws_enc.numel(), blk1.ptr("log_d"), blk1.ptr("d_rounded"), blk1.ptr("src_masks"),
+                blk1.ptr("mel_lens"), blk1.ptr("p_pred"), blk1.ptr("e_pred"), _lib.ptr(pin), st), "ns_forward_durations")
+            blk2 = ws_dec = None
             if isinstance(max_mel_len, (int, np.integer)) and not isinstance(max_mel_len, bool):
                 # CAPACITY MODE (model/modules.py:128-131,204-213 `max_len` semantics): the caller fixes the mel axis, so phase 2
                 # is enqueued right behind phase 1 — no event wait, no host read.  What the synchronous path checks on the host
@@ -389,35 +457,45 @@ class FastSpeech2Align:
                 # (the reference syncs here too: utils/tools.py:92, plus B*L .item() calls at model/modules.py:222)
                 # (a token id outside [0, n_vocab) comes back as mel_len = -1 for its utterance; nn.Embedding raises IndexError)
                 # (the kernel that produces mel_lens also wrote them into pinned host memory: a stream sync, no D2H copy)
+                hint = self._t_hint.get((B, L))
+                if hint is not None and p_targets is None and e_targets is None:
+                    Tc = hint + max(8, hint >> 3)
+                    blk2 = _OutputBlock(phase2_outputs(Tc), dev)
+                    ws_dec = self._workspace("dec", self._ws_bytes("dec", B, L, Tc), sh)
                 self._wait_phase1(dev)
-                ml_host = pin.clone()
-                if int(ml_host.min()) < 0:
-                    bad = [i for i, v in enumerate(ml_host.tolist()) if v < 0]
+                T = int(pin_np.max())
+                if int(pin_np.min()) < 0:
+                    bad = [i for i, v in enumerate(pin_np.tolist()) if v < 0]
                     raise IndexError(f"index out of range in self: token id outside [0, {self._cfg.n_vocab}) in utterance(s) {bad}")
                 if callable(max_mel_len):
-                    T = int(max_mel_len(ml_host.max().to(dev)))
-                    if T < int(ml_host.max()):
-                        raise ValueError(f"max_mel_len() returned {T}, smaller than the longest utterance ({int(ml_host.max())})")
+                    longest = T
+                    T = int(max_mel_len(torch.tensor(longest, device=dev)))
+                    if T < longest:
+                        raise ValueError(f"max_mel_len() returned {T}, smaller than the longest utterance ({longest})")
                 else:
-                    T = int(ml_host.max())
-            n_mel = self._cfg.n_mel
-            mel = torch.empty(B, T, n_mel, **f32)
-            post = torch.empty(B, T, n_mel, **f32)
-            if p_frame:
-                p_pred = torch.empty(B, T, **f32)
-            if e_frame:
-                e_pred = torch.empty(B, T, **f32)
-            mel_masks = torch.empty(B, T, dtype=torch.bool, device=dev)
+                    self._t_hint[(B, L)] = T
+                if blk2 is not None and T > Tc:
+                    blk2 = ws_dec = None
+            if blk2 is None:
+                blk2 = _OutputBlock(phase2_outputs(T), dev)
+                # (T == 0 is still a call: the native side then only fills `status`)
+                ws_dec = self._workspace("dec", self._ws_bytes("dec", B, L, max(T, 1)), sh)
+            else:
+                blk2.layout(phase2_outputs(T))  # same block, offsets for the actual T (it fits: T <= capacity)
             # forward() hands p_targets / e_targets to the variance adaptor in the inference branch too
             # (model/fastspeech2_align.py:70-78): the embedding then comes from bucketize(target)
-            tg = [target("p_targets", p_targets, (B, T)) if p_frame else None,
-                  target("e_targets", e_targets, (B, T)) if e_frame else None]
-            # (T == 0 is still a call: the native side then only fills `status`)
-            ws_dec_bytes = lib.ns_decoder_ws_bytes(self._h, B, L, max(T, 1))
-            ws_dec = self._workspace("dec", ws_dec_bytes)
-            _lib.check(lib.ns_forward_mel(self._h, B, L, T, _lib.ptr(out_mel_lens), float(p_control), float(e_control),
-                                          _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(ws_enc), _lib.ptr(ws_dec), ws_dec.numel(), _lib.ptr(mel),
-                                          _lib.ptr(post), _lib.ptr(p_pred if p_frame else None),
-                                          _lib.ptr(e_pred if e_frame else None), _lib.ptr(mel_masks), _lib.ptr(status), st),
+            tg0 = target("p_targets", p_targets, (B, T)) if p_frame else None
+            tg1 = target("e_targets", e_targets, (B, T)) if e_frame else None
+            _lib.check(lib.ns_forward_mel(self._h, B, L, T, blk1.ptr("mel_lens"), float(p_control), float(e_control),
+                                          _lib.ptr(tg0), _lib.ptr(tg1), _lib.ptr(ws_enc), _lib.ptr(ws_dec), ws_dec.numel(),
+                                          blk2.ptr("mel"), blk2.ptr("post"), blk2.ptr("p_pred") if p_frame else None,
+                                          blk2.ptr("e_pred") if e_frame else None, blk2.ptr("mel_masks"), blk1.ptr("status"), st),
                        "ns_forward_mel")
+            # the GPU is busy with phase 2 from here on: cut the caller's tensors out of the two blocks
+            log_d, d_rounded, src_masks = blk1.view("log_d"), blk1.view("d_rounded"), blk1.view("src_masks")
+            out_mel_lens, status = blk1.view("mel_lens"), blk1.view("status")
+            self.last_status = status
+            mel, post, mel_masks = blk2.view("mel"), blk2.view("post"), blk2.view("mel_masks")
+            p_pred = blk2.view("p_pred") if p_frame else blk1.view("p_pred")
+            e_pred = blk2.view("e_pred") if e_frame else blk1.view("e_pred")
         return (mel, post, p_pred, e_pred, log_d, d_rounded, src_masks, mel_masks, src_lens, out_mel_lens, None, None)
