@@ -115,6 +115,24 @@ int ns_forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens, fl
                    const float* p_targets, const float* e_targets, const void* ws_enc, void* ws_dec, size_t ws_dec_bytes,
                    float* mel, float* postnet_mel, float* p_pred, float* e_pred, uint8_t* mel_mask, int32_t* status, void* stream);
 
+/* Phase 2 on PACKED rows, for variable-length batches.  The reference computes every frame of the padded [B, T] grid and then
+ * zeroes or ignores the frames past each utterance's length (transformer/Layers.py:43,46, model/modules.py:283-284); this
+ * entry point keeps, per utterance, only a window of min(mel_lens[b] + 20, T) frames, lays the windows end to end and runs the
+ * same kernels on sum(windows) rows instead of B*T.  Same arguments, same padded outputs: valid frames are computed by the
+ * same arithmetic (they differ from ns_forward_mel's only by fp32 summation order where a launch picks another tile shape for
+ * the smaller problem), padded frames are rebuilt — mel = the mel_linear bias, predictions 0, PostNet frames within 10 of an
+ * utterance's end computed, all others constants of the weights (the PostNet has no mask between its layers).
+ * mel_lens_host: the caller's HOST copy of mel_lens (what ns_forward_durations wrote to its mel_lens_host): the row count of
+ * the launches comes from it, so this is the synchronous path's entry point.  The call falls back to the dense grid by
+ * itself when packing does not apply (Gaussian regulator, bf16x3 mode) or saves less than 10 % of the rows. */
+int ns_forward_mel_packed(ns_model* m, int B, int L, int T, const int64_t* mel_lens, const int64_t* mel_lens_host,
+                          float p_control, float e_control, const float* p_targets, const float* e_targets, const void* ws_enc,
+                          void* ws_dec, size_t ws_dec_bytes, float* mel, float* postnet_mel, float* p_pred, float* e_pred,
+                          uint8_t* mel_mask, int32_t* status, void* stream);
+/* Activation rows phase 2 of the most recent ns_forward_mel / ns_forward_mel_packed call on this model ran on: B*T on the
+ * dense grid, the sum of the windows when packed (measurement / tests). */
+int64_t ns_last_phase2_rows(const ns_model* m);
+
 /* ---- per-operator entry points (the rows of SURVEY.md §8a; used by the parity tests and by bench.py's
  *      dominant-kernel timing).  `prefix` is the reference module path, e.g.
  *      "mel_decoder.layer_stack.0.slf_attn".  lens[b] = valid length of utterance b (keys/rows >= it are padding). */

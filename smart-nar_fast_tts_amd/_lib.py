@@ -41,7 +41,9 @@ SIGNATURES = {
     "ns_decoder_ws_bytes": (_Z, [_P, _I, _I, _I]),
     "ns_forward_durations": (_I, [_P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ns_forward_mel": (_I, [_P, _I, _I, _I, _P, _F, _F, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _P]),
+    "ns_forward_mel_packed": (_I, [_P, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _P]),
 
+    "ns_last_phase2_rows": (C.c_int64, [_P]),
     "ns_op_ws_bytes": (_Z, [_P, _I, _I]),
     "ns_op_mask_from_lengths": (_I, [_P, _I, _I, _P, _P]),
     "ns_op_sinusoid_table": (_I, [_I, _I, _P, _P]),

@@ -57,6 +57,7 @@ struct ns_model {
   // slot 0 = FFN w_1 (k=9 Conv1D-as-GEMM, the dominant kernel), 1 = fused attention, 2 = PostNet 512->512 k=5 layers.
   // Measurement state, not model state: mutable so that the (const) forward helpers can record into it.
   struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double flops = 0.0; };
+  mutable long long last_rows = 0;  // rows phase 2 of the most recent ns_forward_mel[_packed] ran on (B*T, or the packed windows)
   mutable bool prof = false, prof_active = false;
   mutable ProfSlot prof_slot[NS_PROFILE_SLOTS];
 };
@@ -385,7 +386,7 @@ struct Scratch {  // per-stack temporaries for M rows
 
 static size_t imax(size_t a, size_t b) { return a > b ? a : b; }
 
-static Scratch carve(const ns_config& c, Bump& bp, size_t M, int S) {
+static Scratch carve(const ns_config& c, Bump& bp, size_t M, int S, bool no_split = false) {
   Scratch s;
   const size_t d = c.d_enc;
   s.xa = bp.f(M * d); s.xb = bp.f(M * d);
@@ -397,7 +398,7 @@ static Scratch carve(const ns_config& c, Bump& bp, size_t M, int S) {
   const int hmin = c.n_enc_head < c.n_dec_head ? c.n_enc_head : c.n_dec_head;
   const int hmax = c.n_enc_head > c.n_dec_head ? c.n_enc_head : c.n_dec_head;
   const size_t qtiles = ((size_t)S + 127) / 128;
-  s.att_part_floats = (M / (size_t)S) * qtiles * hmin < ATT_SPLIT_MAX_BLOCKS ? ATT_SPLIT_MAX * (M * d + 2 * M * hmax) : 0;
+  s.att_part_floats = (!no_split && (M / (size_t)S) * qtiles * hmin < ATT_SPLIT_MAX_BLOCKS) ? ATT_SPLIT_MAX * (M * d + 2 * M * hmax) : 0;  // (packed rows never split)
   s.att_part = s.att_part_floats ? bp.f(s.att_part_floats) : nullptr;
   s.tickets = (int*)bp.raw(TICKET_INTS * sizeof(int));
   s.tickets_used = 0;
@@ -420,9 +421,11 @@ extern "C" size_t ns_encoder_ws_bytes(const ns_model* m, int B, int L) {
   carve(m->cfg, bp, (size_t)B * L, L);
   return bp.off + 256;
 }
+static size_t packed_extra_bytes(const ns_config& c, int B, int T);
 extern "C" size_t ns_decoder_ws_bytes(const ns_model* m, int B, int L, int T) {
   (void)L;
-  return ns_op_ws_bytes(m, B, T);
+  if (!m || B <= 0 || T <= 0) return ns_op_ws_bytes(m, B, T);
+  return ns_op_ws_bytes(m, B, T) + packed_extra_bytes(m->cfg, B, T);  // (ns_forward_mel_packed's plan and staging; see forward_mel)
 }
 
 // ------------------------------------------------------------------------------------------- building blocks
@@ -431,6 +434,18 @@ static int check_ready(const ns_model* m) {
   if (!m->ready) return fail("weights not loaded: call ns_set_weight for every key, then ns_finalize_weights (or ns_adopt_arena)");
   return 0;
 }
+
+// Packed rows (kernels.h RowMap): set by the packed phase-2 forward around its launch sequence; every GEMM, row kernel and
+// attention launch issued meanwhile on this thread addresses rows through the map, and "B utterances of S rows" means the
+// Mp packed rows.  nullptr = the dense [B, S] grid.
+struct PackedCtx { RowMap rm; int Mp; };
+static thread_local const PackedCtx* tl_pk = nullptr;
+struct PackedScope {
+  explicit PackedScope(const PackedCtx* pk) { tl_pk = pk; }
+  ~PackedScope() { tl_pk = nullptr; }
+};
+static const RowMap* cur_rm() { return tl_pk ? &tl_pk->rm : nullptr; }
+static int rows_of(int B, int S) { return tl_pk ? tl_pk->Mp : B * S; }
 
 static int gemm(const float* X, int ldx, const float* W, const float* bias, const float* resid, int ldr, float* Y, int ldy,
                 int M, int N, int Cin, int KW, int S, int act, hipStream_t st, const RowEpilogue* epi = nullptr, int epi_mode = EPI_NONE,
@@ -441,6 +456,7 @@ static int gemm(const float* X, int ldx, const float* W, const float* bias, cons
   p.M = M; p.N = N; p.Cin = Cin; p.KW = KW; p.pad = (KW - 1) / 2; p.S = S; p.act = act;
   p.epi = epi ? epi_mode : EPI_NONE;
   if (epi) p.e = *epi;
+  if (tl_pk) { p.rm = tl_pk->rm; p.e.row_b = tl_pk->rm.row_b; p.e.row_t = tl_pk->rm.row_t; }
   // opt-in bf16x3 planes exist for this weight AND the launch is large enough for the 128-row tiles: split-bf16 matrix cores
   if (Wb3 && conv_gemm_b3_ok(M, N, Cin, KW, p.epi)) {
     p.Wb3 = Wb3;
@@ -471,7 +487,7 @@ static int gemm_ln(const float* X, int ldx, const float* W, const float* bias, c
   e.ln_g = g; e.ln_b = b; e.lens = lens;
   if (Wb3 && !conv_gemm_b3_ok(M, N, Cin, KW, EPI_LN) && conv_gemm_b3_ok(M, N, Cin, KW, EPI_NONE)) {
     NS_TRY(gemm(X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st, nullptr, EPI_NONE, Wb3));
-    NS_HIP(launch_layernorm(tmp, g, b, Y, M, N, S, lens, st));
+    NS_HIP(launch_layernorm(tmp, g, b, Y, M, N, S, lens, st, cur_rm()));
     return 0;
   }
   if (fuse_row_epilogue(M, N, Cin)) return gemm(X, ldx, W, bias, resid, N, Y, N, M, N, Cin, KW, S, act, st, &e, EPI_LN, Wb3);
@@ -480,7 +496,7 @@ static int gemm_ln(const float* X, int ldx, const float* W, const float* bias, c
     return gemm(X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st, &e, EPI_LN);
   }
   NS_TRY(gemm(X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st));
-  NS_HIP(launch_layernorm(tmp, g, b, Y, M, N, S, lens, st));
+  NS_HIP(launch_layernorm(tmp, g, b, Y, M, N, S, lens, st, cur_rm()));
   return 0;
 }
 
@@ -515,14 +531,14 @@ struct ProfScope {
 // MultiHeadAttention.forward (transformer/SubLayers.py:29-59); out = LayerNorm(fc(attn) + x), masked when mask_rows
 static int mha(const ns_model* m, const LayerW& L, int d, int H, const float* x, const long long* lens, int B, int S,
                float* out, bool mask_rows, Scratch& sc, hipStream_t st) {
-  const int M = B * S;
+  const int M = rows_of(B, S);
   auto b3 = [&](size_t off) { return off != NO_B3 ? reinterpret_cast<const unsigned short*>(m->P(off)) : nullptr; };
   NS_TRY(gemm(x, d, m->P(L.qkv_w), m->P(L.qkv_b), nullptr, 0, sc.qkv, 3 * d, M, 3 * d, d, 1, S, ACT_NONE, st, nullptr, EPI_NONE, b3(L.qkv_b3)));
   {
     ProfScope ps(m, 1, st, 4.0 * (double)M * (double)S * (double)d);
     NS_TRY(ps.begin());
     NS_HIP(launch_attention(sc.qkv, lens, B, S, H, d / H, sc.att, sc.att_part, sc.att_part_floats,
-                            sc.att_part ? sc.take_tickets(attention_ticket_ints(B, S, H)) : nullptr, st));
+                            (sc.att_part && !tl_pk) ? sc.take_tickets(attention_ticket_ints(B, S, H)) : nullptr, st, cur_rm()));
     NS_TRY(ps.end());
   }
   return gemm_ln(sc.att, d, m->P(L.fc_w), m->P(L.fc_b), x, sc.t1, out, M, d, d, 1, S, ACT_NONE, m->P(L.ln1_g), m->P(L.ln1_b),
@@ -533,7 +549,7 @@ static int mha(const ns_model* m, const LayerW& L, int d, int H, const float* x,
 static int ffn(const ns_model* m, const LayerW& L, int d, const float* x, const long long* lens, int B, int S, float* out,
                bool mask_rows, Scratch& sc, hipStream_t st) {
   const ns_config& c = m->cfg;
-  const int M = B * S;
+  const int M = rows_of(B, S);
   {
     ProfScope ps(m, 0, st, 2.0 * (double)M * (double)c.ffn_k1 * (double)d * (double)c.d_inner);
     NS_TRY(ps.begin());
@@ -571,7 +587,7 @@ static int predictor(const ns_model* m, const PredW& w, const float* x, const lo
                      float* pred, const float* bins, const float* emb, const float* pos, float* x_out, Scratch& sc,
                      hipStream_t st) {
   const ns_config& c = m->cfg;
-  const int M = B * S, F = c.vp_filter;
+  const int M = rows_of(B, S), F = c.vp_filter;
   // conv1d_1 -> relu -> layer_norm_1 (no mask between the layers: model/modules.py:245-274)
   NS_TRY(gemm_ln(x, w.cin, m->P(w.c1), m->P(w.c1_b), nullptr, sc.vp1, sc.vp2, M, F, w.cin, c.vp_kernel, S, ACT_RELU, m->P(w.ln1_g),
                  m->P(w.ln1_b), nullptr, sc, st));
@@ -588,14 +604,14 @@ static int predictor(const ns_model* m, const PredW& w, const float* x, const lo
     return gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st, &e, EPI_LN_PRED);
   NS_TRY(gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st));
   NS_HIP(launch_ln_linear_embed(sc.vp1, m->P(w.ln2_g), m->P(w.ln2_b), m->P(w.lin_w), m->P(w.lin_b), pred, M, F, S, lens,
-                                control, target, bins, c.n_bins, emb, x, pos, x_out, w.cin, st));
+                                control, target, bins, c.n_bins, emb, x, pos, x_out, w.cin, st, cur_rm()));
   return 0;
 }
 
 // PostNet.forward (transformer/Layers.py:169-177); resid != nullptr adds `+ output` of fastspeech2_align.py:85
 static int postnet(const ns_model* m, const float* mel, int B, int T, const float* resid, float* out, Scratch& sc, hipStream_t st) {
   const ns_config& c = m->cfg;
-  const int M = B * T;
+  const int M = rows_of(B, T);
   float* ping = sc.hid;
   float* pong = sc.hid + (size_t)M * c.postnet_dim;
   const float* cur = mel;
@@ -643,7 +659,7 @@ static int decoder_stack(const ns_model* m, float* x, const long long* lens, int
     NS_TRY(fft_block(m, m->dec[i], c.d_dec, c.n_dec_head, cur, lens, B, T, dst, sc, st));
     if (dst != out) { alt = cur; cur = dst; }
   }
-  if (m->dec.empty() && out != x) NS_HIP(hipMemcpyAsync(out, x, (size_t)B * T * c.d_dec * 4, hipMemcpyDeviceToDevice, st));
+  if (m->dec.empty() && out != x) NS_HIP(hipMemcpyAsync(out, x, (size_t)rows_of(B, T) * c.d_dec * 4, hipMemcpyDeviceToDevice, st));
   return 0;
 }
 
@@ -684,10 +700,42 @@ extern "C" int ns_forward_durations(ns_model* m, const int64_t* texts, const int
   return 0;
 }
 
-extern "C" int ns_forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens, float p_control, float e_control,
-                              const float* p_targets, const float* e_targets,
-                              const void* ws_enc, void* ws_dec, size_t ws_bytes, float* mel, float* postnet_mel, float* p_pred,
-                              float* e_pred, uint8_t* mel_mask, int32_t* status, void* stream) {
+// Packed phase 2 (kernels.h RowMap).  The reference runs everything behind the length regulator on the dense [B, T] grid and
+// zeroes / ignores the frames past each utterance's length (transformer/Layers.py:43,46, model/modules.py:283-284; SURVEY.md
+// F3); with variable lengths most of a batch's rows can be such padding.  Here utterance b keeps only its window of
+// min(len[b] + PACK_GUARD, T) frames, the windows are laid end to end (Mp rows instead of B*T) and the same kernels run on
+// them; the padded outputs the caller expects are rebuilt at the end (rowops.hip k_unpack_outputs).  What makes this exact:
+//   * FFT blocks: a valid frame never reads a padded one except as zeros (masked_fill before every convolution, -inf keys);
+//     a window's end is the convolution's zero padding, exactly what the zeroed frames were.
+//   * predictors (no mask between the layers): a valid frame reaches 1 frame past the utterance's end, the guard keeps 20.
+//   * PostNet (no mask at all, input = the mel_linear bias on padded frames): a valid frame reaches 10 frames past the end
+//     (5 layers, reach 2); the guard's first 10 frames are computed from a window that extends 10 further, so they too are
+//     what the dense computation gives; frames beyond are constants of the weights (postnet_constants below).
+// Same arithmetic per row, so valid frames differ from the dense path's only where a launch picks another tile shape for
+// the smaller M (fp32 summation order, ~1e-6).  Needs the lengths on the host (row count), hence the separate entry point.
+static size_t packed_rows(const int64_t* lens_host, int B, int T) {
+  size_t mp = 0;
+  for (int b = 0; b < B; ++b) {
+    long long l = lens_host[b] < 0 ? 0 : lens_host[b];
+    l += PACK_GUARD;
+    mp += (size_t)(l < (long long)T ? l : (long long)T);
+  }
+  return mp;
+}
+constexpr int PN_CONST_ROWS = 32;  // synthetic all-padding utterance: rows [10, 22) are deep padding, [22, 32) see the end of the axis
+static size_t packed_extra_bytes(const ns_config& c, int B, int T) {  // on top of carve(): plan, packed outputs, PostNet constants
+  Bump bp(nullptr, 0);
+  const size_t M = (size_t)B * T;
+  bp.raw(pack_plan_ints(B, M) * sizeof(int));
+  bp.f(M * c.n_mel); bp.f(M * c.n_mel); bp.f(M); bp.f(M); bp.f(M); bp.f(M);
+  bp.f((size_t)PN_CONST_ROWS * c.n_mel); bp.f((size_t)PN_CONST_ROWS * c.n_mel);
+  return bp.off;
+}
+
+static int forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens, const int64_t* lens_host, float p_control, float e_control,
+                       const float* p_targets, const float* e_targets,
+                       const void* ws_enc, void* ws_dec, size_t ws_bytes, float* mel, float* postnet_mel, float* p_pred,
+                       float* e_pred, uint8_t* mel_mask, int32_t* status, void* stream) {
   NS_TRY(check_ready(m));
   if (B <= 0 || L <= 0) return fail("ns_forward_mel: empty batch");
   if (!status) return fail("ns_forward_mel: status [B] is required (a T smaller than an utterance's length must not go unnoticed)");
@@ -706,12 +754,41 @@ extern "C" int ns_forward_mel(ns_model* m, int B, int L, int T, const int64_t* m
   const float* enc_out = be.f((size_t)B * L * c.d_enc);
   const int32_t* cum = (const int32_t*)be.raw((size_t)B * L * sizeof(int32_t));
   const float* dur_keep = be.f((size_t)B * L);
-  Bump bp(ws_dec, ws_bytes);
-  Scratch sc = carve(c, bp, (size_t)B * T, T);
   const long long* lens = (const long long*)mel_lens;
-  const int d = c.d_dec, M = B * T;
+  const int d = c.d_dec;
+  // packed rows: the hard regulator on the exact fp32 path, and only when the windows are a real saving over the grid
+  size_t Mp = 0;
+  bool packed = lens_host && c.length_regulator == 0 && !c.matmul_bf16x3 && !m->dec.empty();
+  if (packed) {
+    Mp = packed_rows(lens_host, B, T);
+    packed = Mp > 0 && Mp < ((size_t)1 << 30) && Mp * 10 <= (size_t)B * T * 9;
+  }
+  const size_t Mrows = packed ? Mp : (size_t)B * T;
+  const int M = (int)Mrows;
+  m->last_rows = (long long)Mrows;
+  Bump bp(ws_dec, ws_bytes);
+  Scratch sc = carve(c, bp, Mrows, T, packed);
 
-  if (c.length_regulator == 1) {
+  PackedCtx pk;
+  memset(&pk, 0, sizeof(pk));
+  float *mel_p = nullptr, *post_p = nullptr, *pp_p = nullptr, *ep_p = nullptr, *pn_in = nullptr, *pn_out = nullptr;
+  if (packed) {
+    int* plan = (int*)bp.raw(pack_plan_ints(B, Mp) * sizeof(int));
+    mel_p = bp.f(Mp * c.n_mel); post_p = bp.f(Mp * c.n_mel); pp_p = bp.f(Mp); ep_p = bp.f(Mp);
+    float* pt_p = bp.f(Mp);
+    float* et_p = bp.f(Mp);
+    pn_in = bp.f((size_t)PN_CONST_ROWS * c.n_mel); pn_out = bp.f((size_t)PN_CONST_ROWS * c.n_mel);
+    if (bp.off > ws_bytes) return fail("ns_forward_mel_packed: workspace too small");
+    pk.Mp = M;
+    NS_HIP(launch_length_regulate_packed(enc_out, cum, B, L, c.d_enc, T, M, sc.xa, lens, status, sc.tickets, TICKET_INTS, plan, &pk.rm, st));
+    // PostNet constants (rowops.hip k_unpack_outputs): the PostNet over an all-padding utterance — every input frame is the
+    // mel_linear bias, zero padding at both ends of a 32-frame axis; frame 21 is deep padding, frames 22..31 see the end
+    NS_HIP(launch_broadcast_row(m->P(m->mel_b), pn_in, PN_CONST_ROWS, c.n_mel, st));
+    NS_TRY(postnet(m, pn_in, 1, PN_CONST_ROWS, pn_in, pn_out, sc, st));  // (dense: the packed scope opens below)
+    // frame-level targets arrive on the padded [B, T] grid
+    if (p_targets && c.pitch_frame_level) { NS_HIP(launch_pack_vector(pk.rm, T, p_targets, pt_p, M, st)); p_targets = pt_p; }
+    if (e_targets && c.energy_frame_level) { NS_HIP(launch_pack_vector(pk.rm, T, e_targets, et_p, M, st)); e_targets = et_p; }
+  } else if (c.length_regulator == 1) {
     NS_HIP(launch_mask_from_lengths(lens, B, T, mel_mask, st));
     // extension: GaussianUpsampling (model/modules.py:166-192) in the LengthRegulator's place;
     // mel_len = sum of the rounded durations, frames past an utterance's own length are zero like pad()'s
@@ -720,6 +797,11 @@ extern "C" int ns_forward_mel(ns_model* m, int B, int L, int T, const int64_t* m
   } else {
     NS_HIP(launch_length_regulate(enc_out, cum, B, L, c.d_enc, T, sc.xa, mel_mask, lens, status, sc.tickets, TICKET_INTS, st));  // + mel mask, status, ticket zeroing
   }
+  PackedScope scope(packed ? &pk : nullptr);
+  float* const mel_dst = packed ? mel_p : mel;
+  float* const post_dst = packed ? post_p : postnet_mel;
+  float* const pp_dst = packed ? pp_p : p_pred;
+  float* const ep_dst = packed ? ep_p : e_pred;
   const float* pos;
   NS_TRY(position_rows(m, m->dec_pos, T, d, sc, &pos, st));
   // frame-level pitch then energy (model/modules.py:139-149); MelDecoder's position add rides on the last
@@ -728,27 +810,52 @@ extern "C" int ns_forward_mel(ns_model* m, int B, int L, int T, const int64_t* m
   float* alt = sc.xb;
   if (c.pitch_frame_level) {
     if (!p_pred) return fail("ns_forward_mel: frame_level pitch needs a p_pred [B,T] output");
-    NS_TRY(predictor(m, m->pred[1], cur, lens, B, T, p_control, p_targets, p_pred, m->P(m->pitch_bins), m->P(m->pitch_emb),
+    NS_TRY(predictor(m, m->pred[1], cur, lens, B, T, p_control, p_targets, pp_dst, m->P(m->pitch_bins), m->P(m->pitch_emb),
                      c.energy_frame_level ? nullptr : pos, alt, sc, st));
     float* t = cur; cur = alt; alt = t;
   }
   if (c.energy_frame_level) {
     if (!e_pred) return fail("ns_forward_mel: frame_level energy needs an e_pred [B,T] output");
-    NS_TRY(predictor(m, m->pred[2], cur, lens, B, T, e_control, e_targets, e_pred, m->P(m->energy_bins), m->P(m->energy_emb), pos,
+    NS_TRY(predictor(m, m->pred[2], cur, lens, B, T, e_control, e_targets, ep_dst, m->P(m->energy_bins), m->P(m->energy_emb), pos,
                      alt, sc, st));
     float* t = cur; cur = alt; alt = t;
   }
   if (!c.pitch_frame_level && !c.energy_frame_level) {
-    NS_HIP(launch_add_pos(cur, pos, alt, M, T, d, st));
+    NS_HIP(launch_add_pos(cur, pos, alt, M, T, d, st, cur_rm()));
     float* t = cur; cur = alt; alt = t;
   }
   m->prof_active = m->prof;  // time only phase 2's launches: one shape per slot (the encoder runs the same kernels at B*L rows)
   int rc = decoder_stack(m, cur, lens, B, T, sc.att, sc, st);
   // note: decoder_stack's last layer writes into sc.att only after its own attention output was consumed
-  if (!rc) rc = gemm(sc.att, d, m->P(m->mel_w), m->P(m->mel_b), nullptr, 0, mel, c.n_mel, M, c.n_mel, d, 1, T, ACT_NONE, st);
-  if (!rc) rc = postnet(m, mel, B, T, mel, postnet_mel, sc, st);
+  if (!rc) rc = gemm(sc.att, d, m->P(m->mel_w), m->P(m->mel_b), nullptr, 0, mel_dst, c.n_mel, M, c.n_mel, d, 1, T, ACT_NONE, st);
+  if (!rc) rc = postnet(m, mel_dst, B, T, mel_dst, post_dst, sc, st);
   m->prof_active = false;
+  if (!rc && packed) {
+    hipError_t e = launch_unpack_outputs(pk.rm, B, T, c.n_mel, lens, mel_p, post_p, c.pitch_frame_level ? pp_p : nullptr,
+                                         c.energy_frame_level ? ep_p : nullptr, m->P(m->mel_b), pn_out + (size_t)21 * c.n_mel, mel, postnet_mel,
+                                         c.pitch_frame_level ? p_pred : nullptr, c.energy_frame_level ? e_pred : nullptr, mel_mask, st);
+    if (e != hipSuccess) rc = fail(std::string("launch_unpack_outputs: ") + hipGetErrorString(e));
+  }
   return rc;
+}
+
+extern "C" int64_t ns_last_phase2_rows(const ns_model* m) { return m ? (int64_t)m->last_rows : 0; }
+
+extern "C" int ns_forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens, float p_control, float e_control,
+                              const float* p_targets, const float* e_targets,
+                              const void* ws_enc, void* ws_dec, size_t ws_bytes, float* mel, float* postnet_mel, float* p_pred,
+                              float* e_pred, uint8_t* mel_mask, int32_t* status, void* stream) {
+  return forward_mel(m, B, L, T, mel_lens, nullptr, p_control, e_control, p_targets, e_targets, ws_enc, ws_dec, ws_bytes, mel, postnet_mel,
+                     p_pred, e_pred, mel_mask, status, stream);
+}
+
+extern "C" int ns_forward_mel_packed(ns_model* m, int B, int L, int T, const int64_t* mel_lens, const int64_t* mel_lens_host,
+                                     float p_control, float e_control, const float* p_targets, const float* e_targets,
+                                     const void* ws_enc, void* ws_dec, size_t ws_bytes, float* mel, float* postnet_mel, float* p_pred,
+                                     float* e_pred, uint8_t* mel_mask, int32_t* status, void* stream) {
+  if (!mel_lens_host) return fail("ns_forward_mel_packed: mel_lens_host (the host copy of mel_lens) is required");
+  return forward_mel(m, B, L, T, mel_lens, mel_lens_host, p_control, e_control, p_targets, e_targets, ws_enc, ws_dec, ws_bytes, mel,
+                     postnet_mel, p_pred, e_pred, mel_mask, status, stream);
 }
 
 // ------------------------------------------------------------------------------------------- per-op entry points

@@ -36,8 +36,9 @@ constexpr int ATT_STRIP_SPLIT_MAX = 8;  // workgroups sharing one 32-query strip
 
 template <int DK>
 __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, const long long* __restrict__ lens,
-                                                    int S, int d, float c_scale, float* __restrict__ out, int nsplit,
-                                                    float* __restrict__ opart, float* __restrict__ mlpart) {
+                                                    int S_grid, int d, float c_scale, float* __restrict__ out, int nsplit,
+                                                    float* __restrict__ opart, float* __restrict__ mlpart,
+                                                    const int* __restrict__ pk_off, const int* __restrict__ pk_win) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BC = 32;                    // keys per tile
   constexpr int CPR = DK / 4;               // 16-B chunks per tile row
@@ -77,9 +78,14 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   // nsplit > 1 (few workgroups, long key axis): workgroup (qt, sp) sweeps only the sp-th contiguous share of the key
   // tiles and leaves an un-normalised partial (O^T, m, l) for k_attention_merge; softmax is exact per part
   const int qt = bx / nsplit, sp = bx - qt * nsplit;
+  // packed rows (kernels.h RowMap): utterance b's rows start at pk_off[b] and number pk_win[b]; the grid is sized for the
+  // longest window, a query tile past this utterance's window has nothing to do
+  const int S = pk_win ? pk_win[b] : S_grid;
+  const size_t row0 = pk_off ? (size_t)pk_off[b] : (size_t)b * S_grid;
+  if (qt * 128 >= S) return;
   const int q = qt * 128 + wid * 32 + qi;
   const int ld = 3 * d;
-  const float* base = qkv + (size_t)b * S * ld + hd * DK;
+  const float* base = qkv + row0 * ld + hd * DK;
   long long len_ll = lens ? lens[b] : (long long)S;
   const int len = (int)(len_ll < S ? len_ll : S);
   const int nkt_all = (len + BC - 1) / BC;
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   }
   const float inv = 1.0f / l_tot;   // lens[b]==0 -> 0 * inf = NaN, as the reference
   if (q < S) {
-    float* dst = out + ((size_t)b * S + q) * d + hd * DK + 4 * h;
+    float* dst = out + (row0 + q) * d + hd * DK + 4 * h;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -600,8 +606,18 @@ __global__ __launch_bounds__(256) void k_attention_merge(const float* __restrict
 }
 
 hipError_t launch_attention(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, float* scratch,
-                            size_t scratch_floats, int* tickets, hipStream_t st) {
+                            size_t scratch_floats, int* tickets, hipStream_t st, const RowMap* rm) {
   if (B <= 0 || S <= 0) return hipSuccess;
+  if (rm) {  // packed rows: one workgroup per (128-query tile of the longest window, head, utterance), no split-key path
+    const int d = H * dk;
+    if ((long long)S * 3 * d * 4 >= (1ll << 31) || (dk != 128 && dk != 64 && dk != 32) || !rm->off || !rm->win) return hipErrorInvalidValue;
+    const float c = 1.4426950408889634f / sqrtf((float)dk);
+    dim3 grid((S + 127) / 128, H, B), block(256);
+    if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out, 1, nullptr, nullptr, rm->off, rm->win);
+    else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out, 1, nullptr, nullptr, rm->off, rm->win);
+    else hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, 1, nullptr, nullptr, rm->off, rm->win);
+    return hipGetLastError();
+  }
   const int d = H * dk;
   if ((long long)S * 3 * d * 4 >= (1ll << 31)) return hipErrorInvalidValue;  // 31-bit descriptor offsets per utterance
   if (dk != 128 && dk != 64 && dk != 32) return hipErrorInvalidValue;
@@ -651,9 +667,9 @@ hipError_t launch_attention(const float* qkv, const long long* lens, int B, int 
   float* opart = nsplit > 1 ? scratch : nullptr;
   float* mlpart = nsplit > 1 ? scratch + (size_t)nsplit * M * d : nullptr;
   dim3 grid(qtiles * nsplit, H, B), block(256);
-  if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart);
-  else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart);
-  else hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart);
+  if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr);
+  else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr);
+  else hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr);
   if (nsplit > 1)
     hipLaunchKernelGGL(k_attention_merge, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, opart, mlpart, (int)M, d, H, dk, nsplit, out);
   return hipGetLastError();

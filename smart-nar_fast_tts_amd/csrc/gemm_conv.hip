@@ -130,9 +130,13 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
   for (int i = 0; i < IA; ++i) {
     const int r = ea(i) * RPI + lr;
     const int m = m0 + r;
-    const int t = (m < p.M) ? (m % p.S) : -1;
+    int t = -1, sw = p.S;  // position of the row in its utterance and that utterance's window (packed rows: kernels.h RowMap)
+    if (m < p.M) {
+      if (p.rm.row_t) { t = p.rm.row_t[m]; sw = p.rm.row_w[m]; }
+      else t = m % p.S;
+    }
     a_base[i] = (r * p.ldx + (ls ^ ((r >> FSH) & FMSK)) * 4) * 4;
-    const int jlo = max(0, p.pad - t), jhi = min(p.KW, p.S + p.pad - t);
+    const int jlo = max(0, p.pad - t), jhi = min(p.KW, sw + p.pad - t);
     a_jlo[i] = (unsigned)jlo;
     a_jn[i] = (t >= 0 && jhi > jlo) ? (unsigned)(jhi - jlo) : 0u;
   }

@@ -7,6 +7,15 @@ namespace ns {
 
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 
+// Packed rows (variable-length batches, api.hip forward_mel packed mode): the M activation rows are the utterances' WINDOWS
+// laid end to end — utterance b owns rows [off[b], off[b] + win[b]), win[b] = min(len[b] + guard, T) — instead of the dense
+// [B, S] grid in which the reference computes (and then discards) every padded frame.  Per row: its utterance, its position
+// in the utterance, and its utterance's window length.  All nullptr = dense grid: b = m / S, t = m % S, window S.
+struct RowMap {
+  const int* row_b; const int* row_t; const int* row_w;  // [M] each
+  const int* off; const int* win;                        // [B + 1], [B]
+};
+
 // Row epilogue of a FULL-ROW tile (N == the tile width, 256 or 512): what the reference applies to every output row right
 // after the contraction, done while the row is still on chip instead of by a second kernel over [M, N].
 //   EPI_LN      Y[m,:] = LayerNorm_N(v[m,:]) * ln_g + ln_b, rows at t >= lens[b] written as zeros when lens != nullptr
@@ -26,6 +35,7 @@ struct RowEpilogue {
   // ([M, N], ldy == N) and the LAST workgroup to finish a row block applies the row epilogue, EPI_LN writing y_out [M, N].
   // ticket: conv_gemm_ticket_ints(M) zeroed ints, used by this launch only; nullptr selects the full-row tile.
   float* y_out; int* ticket;
+  const int* row_b; const int* row_t;  // packed rows (RowMap): utterance / position of row m; nullptr = m / S, m % S
 };
 inline int conv_gemm_ticket_ints(int M) { return (M + 31) / 32; }
 bool conv_gemm_ticket_ok(int M, int N, int Cin);  // shapes the ticketed form covers (row widths 256 / 512)
@@ -44,6 +54,7 @@ struct ConvGemm {
   int act;
   int epi;                      // RowEpi; != EPI_NONE requires conv_gemm_row_epilogue_ok(p)
   RowEpilogue e;
+  RowMap rm;                    // packed rows: tap windows come from row_t / row_w instead of m % S / S
 };
 hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st);
 // opt-in "bf16x3" precision mode (gemm_bf16x3.hip): same contraction from an exact 3-way bf16 split of both operands
@@ -64,26 +75,27 @@ bool conv_gemm_row_epilogue_ok(int M, int N, int Cin);
 constexpr int ATT_SPLIT_MAX = 16, ATT_SPLIT_MAX_BLOCKS = 128;
 // tickets (nullable): attention_ticket_ints(B, S, H) ZEROED ints for the strip kernel's last-arriver merge (small grids)
 inline int attention_ticket_ints(int B, int S, int H) { return B * H * ((S + 31) / 32); }
+// rm (packed rows): utterance b's rows start at rm->off[b] and number rm->win[b] <= S (S = the longest window); no split-key path
 hipError_t launch_attention(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, float* scratch,
-                            size_t scratch_floats, int* tickets, hipStream_t st);
+                            size_t scratch_floats, int* tickets, hipStream_t st, const RowMap* rm = nullptr);
 
 // ---- row kernels (rowops.hip) -----------------------------------------------------------------
 // y = LayerNorm_C(x) * g + b ; rows with t >= lens[b] are written as zero when lens != nullptr
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, int C, int S,
-                            const long long* lens, hipStream_t st);
+                            const long long* lens, hipStream_t st, const RowMap* rm = nullptr);
 // pred[m] = mask ? 0 : dot(LayerNorm_C(x[m]), wlin) + blin            (variance predictor tail)
 // if emb != nullptr additionally  x_out[m,:] = x_in[m,:] + emb[bucketize(pred[m]*control, bins)] (+ pos[t,:])
 hipError_t launch_ln_linear_embed(const float* x, const float* g, const float* b, const float* wlin, const float* blin,
                                   float* pred, int M, int C, int S, const long long* lens, float control,
                                   const float* target, const float* bins, int n_bins, const float* emb, const float* x_in, const float* pos,
-                                  float* x_out, int D, hipStream_t st);
+                                  float* x_out, int D, hipStream_t st, const RowMap* rm = nullptr);
 // out[m,:] = emb[texts[m],:] + pos[t,:]
 // token ids outside [0, n_vocab) read row 0 (and are reported by launch_duration_tail)
 // zero / nzero (nullable): ticket counters of the forward phase this kernel opens, zeroed by it (rowops.hip zero_words);
 // the same pair on launch_length_regulate / launch_gaussian_upsampling
 hipError_t launch_embed_pos(const long long* texts, const float* emb, const float* pos, float* out, int M, int S, int D, int n_vocab,
                             int* zero, int nzero, hipStream_t st);
-hipError_t launch_add_pos(const float* x, const float* pos, float* out, int M, int S, int D, hipStream_t st);
+hipError_t launch_add_pos(const float* x, const float* pos, float* out, int M, int S, int D, hipStream_t st, const RowMap* rm = nullptr);
 hipError_t launch_bucketize(const float* v, int n, const float* bins, int n_edges, long long* idx, hipStream_t st);
 hipError_t launch_mask_from_lengths(const long long* lens, int B, int max_len, uint8_t* mask, hipStream_t st);
 hipError_t launch_sinusoid(int n_pos, int d, float* out, hipStream_t st);
@@ -98,6 +110,22 @@ hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int
 hipError_t launch_duration_tail(const float* log_d, const long long* src_lens, const long long* texts, int n_vocab, int B, int L,
                                 float d_control, float* d_rounded, float* d_keep, int32_t* cum, long long* mel_lens, uint8_t* src_mask,
                                 long long* mel_lens_host /* nullable: device-visible host copy */, hipStream_t st);
+// Packed variant of launch_length_regulate (kernels.h RowMap).  Builds the plan first: win[b] = min(max(mel_lens[b], 0) + guard, T),
+// off = exclusive scan, row maps for the Mp = sum(win) rows (the caller computed the same Mp from its host copy of mel_lens);
+// then gathers the encoder rows into the packed layout (frames at t >= mel_len[b] are zero).  status as launch_length_regulate.
+// plan: int storage for off [B+1], win [B], row_b / row_t / row_w [Mp] — pack_plan_ints(B, Mp) ints; *rm receives the pointers.
+constexpr int PACK_GUARD = 20;  // frames kept past an utterance's end: the PostNet's reach (5 layers x 2) twice over, see api.hip
+inline size_t pack_plan_ints(int B, size_t Mp) { return (size_t)2 * B + 2 + 3 * Mp; }
+hipError_t launch_length_regulate_packed(const float* x, const int32_t* cum, int B, int L, int D, int T, int Mp, float* out,
+                                         const long long* mel_lens, int32_t* status, int* zero, int nzero, int* plan, RowMap* rm,
+                                         hipStream_t st);
+// dst[r, :] = row[:] for r < rows (n % 4 == 0)
+hipError_t launch_broadcast_row(const float* row, float* dst, int rows, int n, hipStream_t st);
+hipError_t launch_pack_vector(const RowMap& rm, int T, const float* src, float* dst, int Mp, hipStream_t st);
+// padded outputs from packed rows (api.hip forward_mel): see k_unpack_outputs in rowops.hip
+hipError_t launch_unpack_outputs(const RowMap& rm, int B, int T, int n_mel, const long long* mel_lens, const float* mel_p, const float* post_p,
+                                 const float* p_p, const float* e_p, const float* mel_bias, const float* post_const, float* mel,
+                                 float* post, float* p_pred, float* e_pred, uint8_t* mel_mask, hipStream_t st);
 hipError_t launch_gaussian_upsampling(const float* x, const float* dur, int B, int L, int D, int T, int T_out,
                                       float* out, float* s, float* w, const long long* own_len, int32_t* status, int* zero, int nzero,
                                       hipStream_t st);

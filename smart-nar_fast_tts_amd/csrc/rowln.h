@@ -211,8 +211,13 @@ __device__ __forceinline__ void row_batch_masks(const RowEpilogue& e, int M, int
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int m = m_first + j * m_step, mc = m < M ? m : M - 1;
-    bb_[j] = mc / S;
-    tt[j] = mc - bb_[j] * S;
+    if (e.row_b) {  // packed rows (kernels.h RowMap)
+      bb_[j] = e.row_b[mc];
+      tt[j] = e.row_t[mc];
+    } else {
+      bb_[j] = mc / S;
+      tt[j] = mc - bb_[j] * S;
+    }
   }
   if (e.lens) {
 #pragma unroll

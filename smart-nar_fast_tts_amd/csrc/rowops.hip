@@ -31,11 +31,13 @@ __device__ __forceinline__ void ln_stats(const float* x, int C, int lane, f32x4 
 template <int NV>
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ g,
                                                     const float* __restrict__ bta, float* __restrict__ y, int M, int C,
-                                                    int S, const long long* __restrict__ lens) {
+                                                    int S, const long long* __restrict__ lens, const int* __restrict__ row_b,
+                                                    const int* __restrict__ row_t) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
-  if (lens && (long long)(m % S) >= lens[m / S]) {  // masked_fill(mask, 0): a padded row is written, never read
+  const int bb = row_b ? row_b[m] : m / S, tt = row_t ? row_t[m] : m % S;  // (packed rows: kernels.h RowMap)
+  if (lens && (long long)tt >= lens[bb]) {  // masked_fill(mask, 0): a padded row is written, never read
     for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<f32x4*>(y + (size_t)m * C + c) = f32x4{0.f, 0.f, 0.f, 0.f};
     return;
   }
@@ -46,13 +48,15 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
 }
 
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, int C, int S,
-                            const long long* lens, hipStream_t st) {
+                            const long long* lens, hipStream_t st, const RowMap* rm) {
   if (M <= 0) return hipSuccess;
   if (C % 4 != 0 || C > 1024) return hipErrorInvalidValue;
   dim3 grid((M + 3) / 4), block(256);
-  if (C <= 256) hipLaunchKernelGGL((k_layernorm<1>), grid, block, 0, st, x, g, b, y, M, C, S, lens);
-  else if (C <= 512) hipLaunchKernelGGL((k_layernorm<2>), grid, block, 0, st, x, g, b, y, M, C, S, lens);
-  else hipLaunchKernelGGL((k_layernorm<4>), grid, block, 0, st, x, g, b, y, M, C, S, lens);
+  const int* rb = rm ? rm->row_b : nullptr;
+  const int* rt = rm ? rm->row_t : nullptr;
+  if (C <= 256) hipLaunchKernelGGL((k_layernorm<1>), grid, block, 0, st, x, g, b, y, M, C, S, lens, rb, rt);
+  else if (C <= 512) hipLaunchKernelGGL((k_layernorm<2>), grid, block, 0, st, x, g, b, y, M, C, S, lens, rb, rt);
+  else hipLaunchKernelGGL((k_layernorm<4>), grid, block, 0, st, x, g, b, y, M, C, S, lens, rb, rt);
   return hipGetLastError();
 }
 
@@ -69,7 +73,8 @@ __global__ __launch_bounds__(256) void k_ln_linear_embed(const float* __restrict
                                                           const float* __restrict__ target,
                                                           const float* __restrict__ bins, int n_edges,
                                                           const float* __restrict__ emb, const float* __restrict__ x_in,
-                                                          const float* __restrict__ pos, float* __restrict__ x_out, int D) {
+                                                          const float* __restrict__ pos, float* __restrict__ x_out, int D,
+                                                          const int* __restrict__ row_b, const int* __restrict__ row_t) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
@@ -77,21 +82,24 @@ __global__ __launch_bounds__(256) void k_ln_linear_embed(const float* __restrict
   float mean, rstd;
   ln_stats<NV>(x + (size_t)m * C, C, lane, v, mean, rstd);
   RowEpilogue e;
+  e.y_out = nullptr; e.ticket = nullptr; e.row_b = nullptr; e.row_t = nullptr;  // (unused by predictor_row_tail)
   e.ln_g = g; e.ln_b = bta; e.lens = lens; e.wlin = wlin; e.blin = blin; e.pred = pred; e.control = control; e.target = target;
   e.bins = bins; e.n_edges = n_edges; e.emb = emb; e.x_in = x_in; e.pos = pos; e.x_out = x_out; e.D = D;
-  const int t = m % S;
-  predictor_row_tail<NV>(v, C, lane, mean, rstd, e, m, t, lens && (long long)t >= lens[m / S]);
+  const int bb = row_b ? row_b[m] : m / S, t = row_t ? row_t[m] : m % S;  // (packed rows: kernels.h RowMap)
+  predictor_row_tail<NV>(v, C, lane, mean, rstd, e, m, t, lens && (long long)t >= lens[bb]);
 }
 
 hipError_t launch_ln_linear_embed(const float* x, const float* g, const float* b, const float* wlin, const float* blin,
                                   float* pred, int M, int C, int S, const long long* lens, float control,
                                   const float* target, const float* bins, int n_bins, const float* emb, const float* x_in, const float* pos,
-                                  float* x_out, int D, hipStream_t st) {
+                                  float* x_out, int D, hipStream_t st, const RowMap* rm) {
   if (M <= 0) return hipSuccess;
   if (C % 4 != 0 || C > 1024 || (emb && D % 4 != 0)) return hipErrorInvalidValue;
   dim3 grid((M + 3) / 4), block(256);
   const int n_edges = n_bins - 1;
-#define NS_ARGS x, g, b, wlin, blin, pred, M, C, S, lens, control, target, bins, n_edges, emb, x_in, pos, x_out, D
+  const int* rb = rm ? rm->row_b : nullptr;
+  const int* rt = rm ? rm->row_t : nullptr;
+#define NS_ARGS x, g, b, wlin, blin, pred, M, C, S, lens, control, target, bins, n_edges, emb, x_in, pos, x_out, D, rb, rt
   if (C <= 256) hipLaunchKernelGGL((k_ln_linear_embed<1>), grid, block, 0, st, NS_ARGS);
   else if (C <= 512) hipLaunchKernelGGL((k_ln_linear_embed<2>), grid, block, 0, st, NS_ARGS);
   else hipLaunchKernelGGL((k_ln_linear_embed<4>), grid, block, 0, st, NS_ARGS);
@@ -140,20 +148,20 @@ hipError_t launch_embed_pos(const long long* texts, const float* emb, const floa
 
 // MelDecoder.forward input: enc_seq + position table (transformer/Models.py:218-235).
 __global__ __launch_bounds__(256) void k_add_pos(const float* __restrict__ x, const float* __restrict__ pos,
-                                                  float* __restrict__ out, int M, int S, int D) {
+                                                  float* __restrict__ out, int M, int S, int D, const int* __restrict__ row_t) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
-  const int t = m % S;
+  const int t = row_t ? row_t[m] : m % S;
   for (int c = lane * 4; c < D; c += 256) {
     f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)m * D + c);
     a += *reinterpret_cast<const f32x4*>(pos + (size_t)t * D + c);
     *reinterpret_cast<f32x4*>(out + (size_t)m * D + c) = a;
   }
 }
-hipError_t launch_add_pos(const float* x, const float* pos, float* out, int M, int S, int D, hipStream_t st) {
+hipError_t launch_add_pos(const float* x, const float* pos, float* out, int M, int S, int D, hipStream_t st, const RowMap* rm) {
   if (M <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_add_pos, dim3((M + 3) / 4), dim3(256), 0, st, x, pos, out, M, S, D);
+  hipLaunchKernelGGL(k_add_pos, dim3((M + 3) / 4), dim3(256), 0, st, x, pos, out, M, S, D, rm ? rm->row_t : nullptr);
   return hipGetLastError();
 }
 
@@ -335,6 +343,151 @@ hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int
   }
   if (D % 4 != 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_length_regulate, dim3((M + 3) / 4), dim3(256), 0, st, x, cum, L, D, T, M, out, mel_mask, mel_lens, status, zero, nzero);
+  return hipGetLastError();
+}
+
+// ---- packed rows (kernels.h RowMap): plan, gather, unpack ------------------------------------------------------------------
+// Plan, one block: win[b] = min(max(mel_lens[b], 0) + PACK_GUARD, T); off = exclusive scan (B is a batch size: serial is fine).
+__global__ void k_pack_plan(const long long* __restrict__ mel_lens, int B, int T, int* __restrict__ off, int* __restrict__ win) {
+  if (threadIdx.x != 0) return;
+  int o = 0;
+  for (int b = 0; b < B; ++b) {
+    long long l = mel_lens[b];
+    if (l < 0) l = 0;
+    l += PACK_GUARD;
+    const int w = (int)(l < (long long)T ? l : (long long)T);
+    off[b] = o;
+    win[b] = w;
+    o += w;
+  }
+  off[B] = o;
+}
+
+// LengthRegulator.LR + pad (model/modules.py:201-218) into the packed layout: row m belongs to the utterance b with
+// off[b] <= m < off[b+1] (binary search), frame t = m - off[b]; also writes the row maps every later kernel reads.
+__global__ __launch_bounds__(256) void k_length_regulate_packed(const float* __restrict__ x, const int32_t* __restrict__ cum, int B, int L,
+                                                                 int D, int T, int Mp, float* __restrict__ out,
+                                                                 const long long* __restrict__ mel_lens, int32_t* __restrict__ status,
+                                                                 const int* __restrict__ off, const int* __restrict__ win,
+                                                                 int* __restrict__ row_b, int* __restrict__ row_t, int* __restrict__ row_w,
+                                                                 int* __restrict__ zero, int nzero) {
+  zero_words(zero, nzero);
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= Mp) return;
+  int lo = 0, hi = B - 1;  // largest b with off[b] <= m
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (off[mid] <= m) lo = mid;
+    else hi = mid - 1;
+  }
+  const int b = lo, t = m - off[b];
+  if (lane == 0) { row_b[m] = b; row_t[m] = t; row_w[m] = win[b]; }
+  const int32_t* cb = cum + (size_t)b * L;
+  const int total = L > 0 ? cb[L - 1] : 0;
+  if (status && t == 0 && lane == 0) status[b] = forward_status(total, T, mel_lens ? mel_lens[b] : 0ll);
+  float* dst = out + (size_t)m * D;
+  if (t >= total) {
+    for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<f32x4*>(dst + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+  lo = 0; hi = L - 1;  // smallest i with cb[i] > t
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (cb[mid] > t) hi = mid;
+    else lo = mid + 1;
+  }
+  const float* src = x + ((size_t)b * L + lo) * D;
+  for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(src + c);
+}
+
+hipError_t launch_length_regulate_packed(const float* x, const int32_t* cum, int B, int L, int D, int T, int Mp, float* out,
+                                         const long long* mel_lens, int32_t* status, int* zero, int nzero, int* plan, RowMap* rm,
+                                         hipStream_t st) {
+  if (B <= 0 || Mp <= 0 || D % 4 != 0 || !plan || !rm || !mel_lens) return hipErrorInvalidValue;
+  int* off = plan;
+  int* win = off + B + 1;
+  int* row_b = win + B + 1;
+  int* row_t = row_b + Mp;
+  int* row_w = row_t + Mp;
+  hipLaunchKernelGGL(k_pack_plan, dim3(1), dim3(64), 0, st, mel_lens, B, T, off, win);
+  hipLaunchKernelGGL(k_length_regulate_packed, dim3((Mp + 3) / 4), dim3(256), 0, st, x, cum, B, L, D, T, Mp, out, mel_lens, status, off, win,
+                     row_b, row_t, row_w, zero, nzero);
+  rm->off = off; rm->win = win; rm->row_b = row_b; rm->row_t = row_t; rm->row_w = row_w;
+  return hipGetLastError();
+}
+
+__global__ void k_broadcast_row(const float* __restrict__ row, float* __restrict__ dst, int total, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) dst[i] = row[i % n];
+}
+hipError_t launch_broadcast_row(const float* row, float* dst, int rows, int n, hipStream_t st) {
+  if (rows <= 0 || n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_broadcast_row, dim3((rows * n + 255) / 256), dim3(256), 0, st, row, dst, rows * n, n);
+  return hipGetLastError();
+}
+
+// dst[m] = src[row_b[m] * T + row_t[m]]: a padded [B, T] vector (forward()'s p_targets / e_targets) onto the packed rows
+__global__ void k_pack_vector(const int* __restrict__ row_b, const int* __restrict__ row_t, int T, const float* __restrict__ src,
+                              float* __restrict__ dst, int Mp) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m < Mp) dst[m] = src[(size_t)row_b[m] * T + row_t[m]];
+}
+hipError_t launch_pack_vector(const RowMap& rm, int T, const float* src, float* dst, int Mp, hipStream_t st) {
+  if (Mp <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pack_vector, dim3((Mp + 255) / 256), dim3(256), 0, st, rm.row_b, rm.row_t, T, src, dst, Mp);
+  return hipGetLastError();
+}
+
+// The caller's padded [B, T, .] outputs from the packed rows.  Frame t of utterance b (window w = win[b], length len):
+//   mel       t < w: the packed row; else the mel_linear bias (mel_linear of a zeroed decoder row, fastspeech2_align.py:83)
+//   p / e     t < w: the packed value (0 past len: the predictors' mask); else 0
+//   mel_mask  t >= len (utils/tools.py:89-97)
+//   postnet   the PostNet has no mask between its layers (transformer/Layers.py:169-177): in the reference a padded frame's value
+//             depends on how far it is from the utterance's last valid frame and from the end of the padded axis — at most
+//             10 frames either way (5 convolutions of reach 2); in between every frame is the same vector.  w == T (the window
+//             is the whole axis): every packed row is what the dense computation gives.  w < T (then len + PACK_GUARD <= T):
+//             t < len + 10 the packed row (its reach stays inside the window's first len + 20 frames); t >= T - 10 row
+//             1 + t - (T - 10) of post_const (frames that see the end of the axis); else row 0 (deep padding).  post_const is
+//             the PostNet applied to an all-padding utterance (api.hip postnet_constants).
+__global__ __launch_bounds__(256) void k_unpack_outputs(const int* __restrict__ off, const int* __restrict__ win, int B, int T, int n_mel,
+                                                         const long long* __restrict__ mel_lens, const float* __restrict__ mel_p,
+                                                         const float* __restrict__ post_p, const float* __restrict__ p_p,
+                                                         const float* __restrict__ e_p, const float* __restrict__ mel_bias,
+                                                         const float* __restrict__ post_const, float* __restrict__ mel,
+                                                         float* __restrict__ post, float* __restrict__ p_pred, float* __restrict__ e_pred,
+                                                         uint8_t* __restrict__ mel_mask) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);  // row of the padded grid
+  if (m >= B * T) return;
+  const int b = m / T, t = m - b * T;
+  const int w = win[b];
+  long long len_ll = mel_lens[b];
+  const int len = (int)(len_ll < 0 ? 0 : (len_ll < (long long)T ? len_ll : (long long)T));
+  const size_t src = (size_t)off[b] + t;
+  const bool in_win = t < w;
+  if (lane == 0) {
+    if (mel_mask) mel_mask[m] = t >= len ? 1 : 0;
+    if (p_pred) p_pred[m] = in_win ? p_p[src] : 0.f;
+    if (e_pred) e_pred[m] = in_win ? e_p[src] : 0.f;
+  }
+  const float* post_src;
+  if (w == T || t < len + 10) post_src = post_p + src * n_mel;
+  else if (t >= T - 10) post_src = post_const + (size_t)(1 + t - (T - 10)) * n_mel;
+  else post_src = post_const;
+  const float* mel_src = in_win ? mel_p + src * n_mel : mel_bias;
+  for (int c = lane; c < n_mel; c += 64) {
+    mel[(size_t)m * n_mel + c] = mel_src[c];
+    post[(size_t)m * n_mel + c] = post_src[c];
+  }
+}
+
+hipError_t launch_unpack_outputs(const RowMap& rm, int B, int T, int n_mel, const long long* mel_lens, const float* mel_p, const float* post_p,
+                                 const float* p_p, const float* e_p, const float* mel_bias, const float* post_const, float* mel,
+                                 float* post, float* p_pred, float* e_pred, uint8_t* mel_mask, hipStream_t st) {
+  if (B <= 0 || T <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_unpack_outputs, dim3((unsigned)(((size_t)B * T + 3) / 4)), dim3(256), 0, st, rm.off, rm.win, B, T, n_mel, mel_lens, mel_p,
+                     post_p, p_p, e_p, mel_bias, post_const, mel, post, p_pred, e_pred, mel_mask);
   return hipGetLastError();
 }
 

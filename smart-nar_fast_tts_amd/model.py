@@ -102,6 +102,9 @@ class FastSpeech2Align:
         self._device = None
         self._arena = None
         self._ws = OrderedDict()  # (kind, stream handle) -> scratch tensor, least recently used first
+        # phase 2 of a synchronous forward runs on packed rows (variable-length batches: include/nar_fs2.h
+        # ns_forward_mel_packed); model_config["padded_rows"] = "dense" or NS_PACKED=0 keeps the reference's padded grid
+        self.packed_rows = model_config.get("padded_rows", "packed" if os.environ.get("NS_PACKED", "1") != "0" else "dense") == "packed"
         self._t_hint = {}         # (B, L) -> T of the last synchronous forward of that shape (capacity guess for the next one)
         self._ws_need = {}        # (kind, B, L, T) -> bytes (ns_*_ws_bytes is a pure function of the config and these)
         self._sd = OrderedDict()  # host copy of what load_state_dict received (for state_dict() / .to())
@@ -445,6 +448,7 @@ class FastSpeech2Align:
                 _lib.ptr(ws_enc), ws_enc.numel(), blk1.ptr("log_d"), blk1.ptr("d_rounded"), blk1.ptr("src_masks"),
                 blk1.ptr("mel_lens"), blk1.ptr("p_pred"), blk1.ptr("e_pred"), _lib.ptr(pin), st), "ns_forward_durations")
             blk2 = ws_dec = None
+            lens_on_host = False
             if isinstance(max_mel_len, (int, np.integer)) and not isinstance(max_mel_len, bool):
                 # CAPACITY MODE (model/modules.py:128-131,204-213 `max_len` semantics): the caller fixes the mel axis, so phase 2
                 # is enqueued right behind phase 1 — no event wait, no host read.  What the synchronous path checks on the host
@@ -463,6 +467,7 @@ class FastSpeech2Align:
                     blk2 = _OutputBlock(phase2_outputs(Tc), dev)
                     ws_dec = self._workspace("dec", self._ws_bytes("dec", B, L, Tc), sh)
                 self._wait_phase1(dev)
+                lens_on_host = True
                 T = int(pin_np.max())
                 if int(pin_np.min()) < 0:
                     bad = [i for i, v in enumerate(pin_np.tolist()) if v < 0]
@@ -486,11 +491,15 @@ class FastSpeech2Align:
             # (model/fastspeech2_align.py:70-78): the embedding then comes from bucketize(target)
             tg0 = target("p_targets", p_targets, (B, T)) if p_frame else None
             tg1 = target("e_targets", e_targets, (B, T)) if e_frame else None
-            _lib.check(lib.ns_forward_mel(self._h, B, L, T, blk1.ptr("mel_lens"), float(p_control), float(e_control),
-                                          _lib.ptr(tg0), _lib.ptr(tg1), _lib.ptr(ws_enc), _lib.ptr(ws_dec), ws_dec.numel(),
-                                          blk2.ptr("mel"), blk2.ptr("post"), blk2.ptr("p_pred") if p_frame else None,
-                                          blk2.ptr("e_pred") if e_frame else None, blk2.ptr("mel_masks"), blk1.ptr("status"), st),
-                       "ns_forward_mel")
+            tail = (float(p_control), float(e_control), _lib.ptr(tg0), _lib.ptr(tg1), _lib.ptr(ws_enc), _lib.ptr(ws_dec), ws_dec.numel(),
+                    blk2.ptr("mel"), blk2.ptr("post"), blk2.ptr("p_pred") if p_frame else None,
+                    blk2.ptr("e_pred") if e_frame else None, blk2.ptr("mel_masks"), blk1.ptr("status"), st)
+            if lens_on_host and self.packed_rows:
+                # variable-length batches: phase 2 on packed rows (include/nar_fs2.h ns_forward_mel_packed) — the native side
+                # takes the row count from the host copy of mel_lens and falls back to the dense grid when packing saves < 10 %
+                _lib.check(lib.ns_forward_mel_packed(self._h, B, L, T, blk1.ptr("mel_lens"), _lib.ptr(pin), *tail), "ns_forward_mel_packed")
+            else:
+                _lib.check(lib.ns_forward_mel(self._h, B, L, T, blk1.ptr("mel_lens"), *tail), "ns_forward_mel")
             # the GPU is busy with phase 2 from here on: cut the caller's tensors out of the two blocks
             log_d, d_rounded, src_masks = blk1.view("log_d"), blk1.view("d_rounded"), blk1.view("src_masks")
             out_mel_lens, status = blk1.view("mel_lens"), blk1.view("status")

@@ -598,11 +598,20 @@ def test_max_mel_len_global_pad_mode():
     Utterances that were already padded keep bit-identical results; shapes follow max_mel_len."""
     meta, z = load_golden("e2e_tiny_padded_src")
     cfg, sd, m = gpu_model(meta)
-    base = run_gpu(m, z, meta)
-    T = base[0].shape[1]
-    with torch.no_grad():
-        padded = m(dev(z["speakers"]), dev(z["texts"]), dev(z["in_src_lens"]), int(meta["L"]), max_mel_len=T + 9)
-        via_fn = m(dev(z["speakers"]), dev(z["texts"]), dev(z["in_src_lens"]), int(meta["L"]), max_mel_len=lambda t: int(t) + 9)
+    m.packed_rows = False  # the bit-identity statements below are about the padded GRID (capacity mode always runs on it)
+    try:
+        base = run_gpu(m, z, meta)
+        T = base[0].shape[1]
+        with torch.no_grad():
+            padded = m(dev(z["speakers"]), dev(z["texts"]), dev(z["in_src_lens"]), int(meta["L"]), max_mel_len=T + 9)
+            via_fn = m(dev(z["speakers"]), dev(z["texts"]), dev(z["in_src_lens"]), int(meta["L"]), max_mel_len=lambda t: int(t) + 9)
+            m.packed_rows = True  # the synchronous path's default: packed rows, same values up to fp32 summation order
+            via_packed = m(dev(z["speakers"]), dev(z["texts"]), dev(z["in_src_lens"]), int(meta["L"]), max_mel_len=lambda t: int(t) + 9)
+    finally:
+        m.packed_rows = True
+    assert via_packed[1].shape == padded[1].shape and torch.equal(via_packed[7], padded[7]) and torch.equal(via_packed[9], padded[9])
+    close(via_packed[1], padded[1].cpu().numpy(), 2e-5, "global-pad mode on packed rows vs the grid (postnet mel, every frame)")
+    close(via_packed[0], padded[0].cpu().numpy(), 2e-5, "global-pad mode on packed rows vs the grid (mel, every frame)")
     assert padded[0].shape[1] == T + 9 and padded[7].shape[1] == T + 9
     assert torch.equal(padded[1], via_fn[1])
     assert torch.equal(padded[9], base[9])
@@ -626,6 +635,7 @@ def test_capacity_mode_is_sync_free_and_bit_identical():
 
     meta, z = load_golden("e2e_tiny_padded_src")
     cfg, sd, m = gpu_model(meta)
+    m.packed_rows = False  # capacity mode runs on the padded grid (the host never learns the lengths): compare grid with grid
     base = run_gpu(m, z, meta)
     T = base[0].shape[1]
     args = (dev(z["speakers"]), dev(z["texts"]), dev(z["in_src_lens"]), int(meta["L"]))
@@ -664,6 +674,7 @@ def test_capacity_mode_is_sync_free_and_bit_identical():
     # the C-ABI refuses to run without a status buffer (a C caller cannot truncate silently)
     rc = m._lib.ns_forward_mel(m._h, 1, 1, 1, None, 1.0, 1.0, None, None, None, None, 0, None, None, None, None, None, None, None)
     assert rc != 0 and b"status" in m._lib.ns_last_error()
+    m.packed_rows = True
 
 
 def test_rejected_state_dict_leaves_the_loaded_model_usable():
@@ -779,6 +790,60 @@ def test_ragged_batch_vs_oracle():
     close(tf[3], ref[3].numpy(), MEL_TOL, "energy")
     print("ragged: mel", close(tf[0], ref[0].numpy(), MEL_TOL, "mel (all rows, padded included)"),
           "postnet", close(tf[1], ref[1].numpy(), MEL_TOL, "postnet mel (all rows, padded included)"))
+
+
+def test_packed_rows_match_the_dense_grid_on_ragged_batches():
+    """include/nar_fs2.h ns_forward_mel_packed: phase 2 of a variable-length batch runs on the utterances' windows
+    (min(len + 20, T) frames each) laid end to end instead of the reference's padded [B, T] grid
+    (transformer/Layers.py:43,46, model/modules.py:283-284: padded frames are computed, then zeroed or ignored).
+    Against the dense grid of the same build, bucket decisions pinned by the dense run's own pitch / energy values: every
+    returned tensor on EVERY frame, padded ones included — integers and masks exact, floats within fp32 summation noise
+    (a smaller launch may pick another tile shape) — and the packed run must really have run on fewer rows."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    cases = [("ljspeech", 8.0, np.array([128, 10, 64, 1, 100, 33, 127, 17, 128, 5, 77, 2]), 128),
+             ("ljspeech", 31.0, np.array([128, 16, 90, 40, 128, 61, 20, 110]), 128),   # long-form: T_pad ~ 3900
+             ("ljspeech", 3.0, np.array([60, 5, 20, 2, 40]), 60),                       # windows of a few dozen frames
+             ("d512", 8.0, np.array([100, 30, 128, 64, 12, 90]), 128)]
+    for cfg_name, fpp, lens, L in cases:
+        _MODEL.clear()
+        meta = dict(config=cfg_name, weight_seed=0, frames_per_phoneme=fpp, dur_weight_scale=0.25)
+        cfg, sd = weights_for(meta)
+        inp = wl.synth_inputs(len(lens), L, seed=9, src_lens=lens)
+        args = (dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3])
+        models = {}
+        for mode in ("dense", "packed"):
+            m = FastSpeech2Align(wl.preprocess_config(), dict(cfg, padded_rows=mode)).to("cuda").eval()
+            m.load_state_dict(sd)
+            models[mode] = m
+        with torch.no_grad():
+            free = models["dense"](*args)
+            pin = dict(p_targets=free[2].clone(), e_targets=free[3].clone())
+            dense = models["dense"](*args, **pin)
+            rows_dense = models["dense"]._lib.ns_last_phase2_rows(models["dense"]._h)
+            packed = models["packed"](*args, **pin)
+            rows_packed = models["packed"]._lib.ns_last_phase2_rows(models["packed"]._h)
+            packed_free = models["packed"](*args)
+            torch.cuda.synchronize()
+        B, T = dense[0].shape[0], dense[0].shape[1]
+        ml = dense[9].cpu().numpy()
+        assert rows_dense == B * T and rows_packed == int(np.minimum(ml + 20, T).sum()) and rows_packed < 0.9 * rows_dense, \
+            (cfg_name, rows_dense, rows_packed)
+        for i in (4, 5, 6, 7, 9):
+            assert torch.equal(packed[i], dense[i]) and torch.equal(packed_free[i], free[i]), (cfg_name, NAMES[i])
+        worst = {}
+        for i in (0, 1, 2, 3):
+            assert packed[i].shape == dense[i].shape
+            worst[NAMES[i]] = float((packed[i] - dense[i]).abs().max())
+            assert torch.isfinite(packed[i]).all()
+        print("packed vs dense", cfg_name, "fpp", fpp, "rows", rows_packed, "of", rows_dense, worst)
+        assert worst["output"] < 2e-5 and worst["postnet_output"] < 2e-5 and worst["e_predictions"] < 2e-4, worst
+        # with targets the prediction itself is returned: pitch does not depend on the targets, energy on the pitch bucket only
+        assert worst["p_predictions"] < 2e-3 * max(1.0, float(dense[2].abs().max())), worst
+        # free-running: the packed run takes its own bucket decisions; frame counts and masks still agree, values stay finite
+        assert torch.isfinite(packed_free[1]).all()
+    _MODEL.clear()
 
 
 def test_bf16x3_mode_vs_oracle_and_fp32_path():
