@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="profiling runs: only warm-up + timed steps (no latency leg, no pipelined leg, no CPU baseline), so that a "
                          "kernel trace holds exactly (warmup + steps) forwards of the workload")
-    ap.add_argument("--ragged", action="store_true", help="ragged utterance lengths instead of the uniform BASELINE batch")
+    ap.add_argument("--ragged", action="store_true", help="ragged utterance lengths instead of the uniform BASELINE batch (phase 2 then runs on packed rows; NS_PACKED=0 keeps the padded grid)")
     ap.add_argument("--streams", type=int, default=1, help="issue consecutive steps round-robin on this many HIP streams")
     ap.add_argument("--global-pad", action="store_true", help="pad every shard to the global max mel length (all-reduce MAX)")
     ap.add_argument("--matmul", choices=["fp32", "bf16x3"], default="fp32",
@@ -202,6 +202,7 @@ def main():
     devices = [{"rank": rank, "device": f"cuda:{dev_index}", "name": torch.cuda.get_device_name(dev)}]
     # per-rank view (SURVEY.md §8e "scaling risks": per-shard T_pad differs, so load imbalance must be visible in a SCALE line)
     per_rank = [{"rank": rank, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "T_pad": T_pad, "valid_frames": frames,
+                 "rows_phase2": int(model._lib.ns_last_phase2_rows(model._h)),  # B*T_pad on the grid, fewer on packed rows (ragged batches)
                  "hsa_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "omp_num_threads": os.environ.get("OMP_NUM_THREADS"),
                  "launcher": os.environ.get("NS_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "none")}]
     world_seen = 1
@@ -343,6 +344,40 @@ def main():
                                             "p50_ms": round(float(np.median(latc)), 3), "min_ms": round(min(latc), 3),
                                             "max_ms": round(max(latc), 3), "n": len(latc), "status": model.check_status(),
                                             "bit_identical_to_sync_path": bool(torch.equal(oc[1], o1[1]) and torch.equal(oc[9], o1[9]))}
+
+    if args.gpus == 1 and not args.no_extras and not b3:
+        # Variable-length batches (BASELINE.json config 5: "variable-length masking stress"): the same model on a RAGGED batch of
+        # this workload's shape — phoneme counts uniform in [L/8, L], one utterance at L — with phase 2 on packed rows
+        # (include/nar_fs2.h ns_forward_mel_packed, the synchronous path's default) and on the reference's padded [B, T] grid.
+        # A secondary figure: the headline value above is BASELINE.json's uniform batch.
+        rr = np.random.RandomState(7)
+        rl = rr.randint(max(1, L // 8), L + 1, size=B_shard)
+        rl[0] = L
+        rs_, rt_, rln_, _ = wl.synth_inputs(B_shard, L, seed=0, src_lens=rl)
+        ra = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (rs_, rt_, rln_)]
+        vl = {}
+        keep = model.packed_rows
+        try:
+            for mode in ("packed", "grid"):
+                model.packed_rows = mode == "packed"
+                with torch.no_grad():
+                    for _ in range(3):
+                        ro = model(ra[0], ra[1], ra[2], L)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        ro = model(ra[0], ra[1], ra[2], L)
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / 10
+                vf = int(ro[9].sum())
+                vl[mode] = {"ms_per_step": round(dt * 1e3, 3), "value": round(vf / dt, 1), "unit": "frames/s",
+                            "rows_phase2": int(model._lib.ns_last_phase2_rows(model._h))}
+                vl["T_pad"], vl["valid_frames"] = int(ro[0].shape[1]), vf
+        finally:
+            model.packed_rows = keep
+        vl["speedup"] = round(vl["grid"]["ms_per_step"] / vl["packed"]["ms_per_step"], 3)
+        vl["workload"] = f"{args.workload} with ragged lengths (phoneme counts uniform in [L/8, L], B={B_shard})"
+        res["variable_length"] = vl
 
     if args.gpus == 1 and not args.no_cpu_baseline and not args.no_extras:
         # CPU baseline beside it: the oracle (a torch-CPU restatement of the reference forward, "port") on this box's

@@ -780,7 +780,12 @@ static int forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens
     pn_in = bp.f((size_t)PN_CONST_ROWS * c.n_mel); pn_out = bp.f((size_t)PN_CONST_ROWS * c.n_mel);
     if (bp.off > ws_bytes) return fail("ns_forward_mel_packed: workspace too small");
     pk.Mp = M;
-    NS_HIP(launch_length_regulate_packed(enc_out, cum, B, L, c.d_enc, T, M, sc.xa, lens, status, sc.tickets, TICKET_INTS, plan, &pk.rm, st));
+    NS_HIP(launch_length_regulate_packed(enc_out, cum, B, L, c.d_enc, T, M, c.n_dec_head, sc.xa, lens, status, sc.tickets, TICKET_INTS, plan, &pk.rm, st));
+    for (int b = 0; b < B; ++b) {  // the attention work list's length, from the same lengths the device plan reads
+      long long l = (lens_host[b] < 0 ? 0 : lens_host[b]) + PACK_GUARD;
+      if (l > T) l = T;
+      pk.rm.att_wgs += (int)((l + 127) / 128) * c.n_dec_head;
+    }
     // PostNet constants (rowops.hip k_unpack_outputs): the PostNet over an all-padding utterance — every input frame is the
     // mel_linear bias, zero padding at both ends of a 32-frame axis; frame 21 is deep padding, frames 22..31 see the end
     NS_HIP(launch_broadcast_row(m->P(m->mel_b), pn_in, PN_CONST_ROWS, c.n_mel, st));

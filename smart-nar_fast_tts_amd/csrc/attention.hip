@@ -38,7 +38,8 @@ template <int DK>
 __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, const long long* __restrict__ lens,
                                                     int S_grid, int d, float c_scale, float* __restrict__ out, int nsplit,
                                                     float* __restrict__ opart, float* __restrict__ mlpart,
-                                                    const int* __restrict__ pk_off, const int* __restrict__ pk_win) {
+                                                    const int* __restrict__ pk_off, const int* __restrict__ pk_win,
+                                                    const int* __restrict__ att_off, const int* __restrict__ att_order, int nutt) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BC = 32;                    // keys per tile
   constexpr int CPR = DK / 4;               // 16-B chunks per tile row
@@ -63,7 +64,21 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   // head's K and V through its own L2 (profiles/r02: 4.5x the algorithmic bytes at config 2).  Handing XCD x the x-th
   // contiguous slice of the (batch, head, query tile) order instead keeps all query tiles of a head on one L2.
   int bx, hd, b;
-  {
+  if (att_off) {
+    // packed rows: a flat work list, longest utterances first (kernels.h RowMap::att_off); workgroup i belongs to the rank r
+    // with att_off[r] <= i < att_off[r + 1], and is query tile (i - att_off[r]) % qtiles of head (i - att_off[r]) / qtiles
+    const int i = blockIdx.x;
+    int lo = 0, hi = nutt - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (att_off[mid] <= i) lo = mid;
+      else hi = mid - 1;
+    }
+    b = att_order[lo];
+    const int local = i - att_off[lo], qtiles = (pk_win[b] + 127) / 128;
+    hd = local / qtiles;
+    bx = local - hd * qtiles;
+  } else {
     const int nx = gridDim.x, ny = gridDim.y, nblk = nx * ny * gridDim.z;
     const int L = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
     const int q8 = nblk >> 3, r8 = nblk & 7, xcd = L & 7;
@@ -612,10 +627,13 @@ hipError_t launch_attention(const float* qkv, const long long* lens, int B, int 
     const int d = H * dk;
     if ((long long)S * 3 * d * 4 >= (1ll << 31) || (dk != 128 && dk != 64 && dk != 32) || !rm->off || !rm->win) return hipErrorInvalidValue;
     const float c = 1.4426950408889634f / sqrtf((float)dk);
-    dim3 grid((S + 127) / 128, H, B), block(256);
-    if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out, 1, nullptr, nullptr, rm->off, rm->win);
-    else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out, 1, nullptr, nullptr, rm->off, rm->win);
-    else hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, 1, nullptr, nullptr, rm->off, rm->win);
+    if (!rm->att_off || !rm->att_order || rm->att_wgs <= 0) return hipErrorInvalidValue;
+    dim3 grid(rm->att_wgs), block(256);
+#define NS_PK rm->off, rm->win, rm->att_off, rm->att_order, B
+    if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out, 1, nullptr, nullptr, NS_PK);
+    else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out, 1, nullptr, nullptr, NS_PK);
+    else hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, 1, nullptr, nullptr, NS_PK);
+#undef NS_PK
     return hipGetLastError();
   }
   const int d = H * dk;
@@ -667,9 +685,9 @@ hipError_t launch_attention(const float* qkv, const long long* lens, int B, int 
   float* opart = nsplit > 1 ? scratch : nullptr;
   float* mlpart = nsplit > 1 ? scratch + (size_t)nsplit * M * d : nullptr;
   dim3 grid(qtiles * nsplit, H, B), block(256);
-  if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr);
-  else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr);
-  else hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr);
+  if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr, nullptr, nullptr, 0);
+  else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr, nullptr, nullptr, 0);
+  else hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr, nullptr, nullptr, 0);
   if (nsplit > 1)
     hipLaunchKernelGGL(k_attention_merge, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, opart, mlpart, (int)M, d, H, dk, nsplit, out);
   return hipGetLastError();

@@ -14,6 +14,11 @@ enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 struct RowMap {
   const int* row_b; const int* row_t; const int* row_w;  // [M] each
   const int* off; const int* win;                        // [B + 1], [B]
+  // attention work list (attention.hip, packed launches): utterances in order of DESCENDING window, att_order[r] = the r-th
+  // longest; att_off[r] = first workgroup of rank r, att_off[B] = att_wgs = sum_b ceil(win[b] / 128) * H.  Longest sweeps first:
+  // the hardware hands workgroups to CUs in launch order, so the launch finishes when the work does, not when the XCD that drew
+  // the longest utterance does.
+  const int* att_off; const int* att_order; int att_wgs;
 };
 
 // Row epilogue of a FULL-ROW tile (N == the tile width, 256 or 512): what the reference applies to every output row right
@@ -51,6 +56,9 @@ struct ConvGemm {
   const float* resid; int ldr;  // [M, N] or nullptr
   float* Y; int ldy;
   int M, N, Cin, KW, pad, S;
+  int m_base;                   // rows of the full matrix ahead of X / Y / resid row 0 (a launch over a row range of a larger
+                                // problem, gemm_conv.hip split plan): the utterance position of row m is that of row m_base + m.
+                                // Plain epilogues only (epi == EPI_NONE).
   int act;
   int epi;                      // RowEpi; != EPI_NONE requires conv_gemm_row_epilogue_ok(p)
   RowEpilogue e;
@@ -115,8 +123,9 @@ hipError_t launch_duration_tail(const float* log_d, const long long* src_lens, c
 // then gathers the encoder rows into the packed layout (frames at t >= mel_len[b] are zero).  status as launch_length_regulate.
 // plan: int storage for off [B+1], win [B], row_b / row_t / row_w [Mp] — pack_plan_ints(B, Mp) ints; *rm receives the pointers.
 constexpr int PACK_GUARD = 20;  // frames kept past an utterance's end: the PostNet's reach (5 layers x 2) twice over, see api.hip
-inline size_t pack_plan_ints(int B, size_t Mp) { return (size_t)2 * B + 2 + 3 * Mp; }
-hipError_t launch_length_regulate_packed(const float* x, const int32_t* cum, int B, int L, int D, int T, int Mp, float* out,
+inline size_t pack_plan_ints(int B, size_t Mp) { return (size_t)4 * B + 4 + 3 * Mp; }
+// H: attention heads of the stack that will run on these rows (the plan's attention work list is per head)
+hipError_t launch_length_regulate_packed(const float* x, const int32_t* cum, int B, int L, int D, int T, int Mp, int H, float* out,
                                          const long long* mel_lens, int32_t* status, int* zero, int nzero, int* plan, RowMap* rm,
                                          hipStream_t st);
 // dst[r, :] = row[:] for r < rows (n % 4 == 0)

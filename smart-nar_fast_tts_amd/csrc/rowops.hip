@@ -347,20 +347,36 @@ hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int
 }
 
 // ---- packed rows (kernels.h RowMap): plan, gather, unpack ------------------------------------------------------------------
-// Plan, one block: win[b] = min(max(mel_lens[b], 0) + PACK_GUARD, T); off = exclusive scan (B is a batch size: serial is fine).
-__global__ void k_pack_plan(const long long* __restrict__ mel_lens, int B, int T, int* __restrict__ off, int* __restrict__ win) {
-  if (threadIdx.x != 0) return;
-  int o = 0;
-  for (int b = 0; b < B; ++b) {
+// Plan, one block: win[b] = min(max(mel_lens[b], 0) + PACK_GUARD, T); off = exclusive scan (B is a batch size: serial is fine);
+// attention work list: utterances ranked by descending window (ties by index), att_off = exclusive scan of
+// ceil(win / 128) * H in rank order.
+__global__ __launch_bounds__(256) void k_pack_plan(const long long* __restrict__ mel_lens, int B, int T, int H, int* __restrict__ off,
+                                                    int* __restrict__ win, int* __restrict__ att_off, int* __restrict__ att_order) {
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
     long long l = mel_lens[b];
     if (l < 0) l = 0;
     l += PACK_GUARD;
-    const int w = (int)(l < (long long)T ? l : (long long)T);
-    off[b] = o;
-    win[b] = w;
-    o += w;
+    win[b] = (int)(l < (long long)T ? l : (long long)T);
   }
-  off[B] = o;
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const int w = win[b];
+    int rank = 0;
+    for (int o = 0; o < B; ++o) rank += (win[o] > w || (win[o] == w && o < b)) ? 1 : 0;
+    att_order[rank] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int o = 0, a = 0;
+    for (int b = 0; b < B; ++b) {
+      off[b] = o;
+      o += win[b];
+      att_off[b] = a;
+      a += ((win[att_order[b]] + 127) / 128) * H;
+    }
+    off[B] = o;
+    att_off[B] = a;
+  }
 }
 
 // LengthRegulator.LR + pad (model/modules.py:201-218) into the packed layout: row m belongs to the utterance b with
@@ -401,16 +417,19 @@ __global__ __launch_bounds__(256) void k_length_regulate_packed(const float* __r
   for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(src + c);
 }
 
-hipError_t launch_length_regulate_packed(const float* x, const int32_t* cum, int B, int L, int D, int T, int Mp, float* out,
+hipError_t launch_length_regulate_packed(const float* x, const int32_t* cum, int B, int L, int D, int T, int Mp, int H, float* out,
                                          const long long* mel_lens, int32_t* status, int* zero, int nzero, int* plan, RowMap* rm,
                                          hipStream_t st) {
   if (B <= 0 || Mp <= 0 || D % 4 != 0 || !plan || !rm || !mel_lens) return hipErrorInvalidValue;
   int* off = plan;
   int* win = off + B + 1;
-  int* row_b = win + B + 1;
+  int* att_off = win + B + 1;
+  int* att_order = att_off + B + 1;
+  int* row_b = att_order + B + 1;
   int* row_t = row_b + Mp;
   int* row_w = row_t + Mp;
-  hipLaunchKernelGGL(k_pack_plan, dim3(1), dim3(64), 0, st, mel_lens, B, T, off, win);
+  hipLaunchKernelGGL(k_pack_plan, dim3(1), dim3(256), 0, st, mel_lens, B, T, H, off, win, att_off, att_order);
+  rm->att_off = att_off; rm->att_order = att_order;  // (att_wgs: the caller's, from its host copy of the lengths)
   hipLaunchKernelGGL(k_length_regulate_packed, dim3((Mp + 3) / 4), dim3(256), 0, st, x, cum, B, L, D, T, Mp, out, mel_lens, status, off, win,
                      row_b, row_t, row_w, zero, nzero);
   rm->off = off; rm->win = win; rm->row_b = row_b; rm->row_t = row_t; rm->row_w = row_w;

@@ -36,7 +36,7 @@ def main():
     rs = np.random.RandomState(args.seed)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
     worst = {"mel": 0.0, "postnet": 0.0, "energy": 0.0, "log_d": 0.0}
-    checked = skipped = 0
+    checked = skipped = packed = 0
     cache = {}
     t_start = time.time()
     for it in range(args.iters):
@@ -91,9 +91,10 @@ def main():
             worst[name] = max(worst[name], err)
             assert err < tol and bool((torch.isnan(g) == torch.isnan(r)).all()), (tag, name, err)
         checked += 1
+        packed += int(m._lib.ns_last_phase2_rows(m._h) < tf[0].shape[0] * tf[0].shape[1])  # phase 2 ran on packed rows (nar_fs2.h)
         if (it + 1) % 25 == 0:
             print(f"[{it + 1}/{args.iters}] checked {checked} skipped {skipped} worst {worst} ({time.time() - t_start:.0f} s)", flush=True)
-    print(f"FUZZ OK: {checked} cases checked, {skipped} skipped (duration on a rounding boundary / empty), worst errors {worst}")
+    print(f"FUZZ OK: {checked} cases checked ({packed} of them with phase 2 on packed rows), {skipped} skipped (duration on a rounding boundary / empty), worst errors {worst}")
 
 
 if __name__ == "__main__":
