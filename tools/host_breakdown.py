@@ -18,7 +18,7 @@ def wrap(name):
     return g
 class L2:
     def __getattr__(self, n):
-        return wrap(n) if n in ("ns_forward_durations", "ns_forward_mel") else getattr(lib, n)
+        return wrap(n) if n in ("ns_forward_durations", "ns_forward_mel", "ns_forward_mel_packed") else getattr(lib, n)
 m._lib = L2()
 w0 = m._wait_phase1
 def w(dev):
@@ -30,7 +30,7 @@ with torch.no_grad():
         T.clear(); torch.cuda.synchronize(); t0 = time.perf_counter()
         o = m(a[0], a[1], a[2], L)
         t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-        d, wt, ml = T["ns_forward_durations"][0], T["wait"][0], T["ns_forward_mel"][0]
+        d, wt, ml = T["ns_forward_durations"][0], T["wait"][0], (T.get("ns_forward_mel_packed") or T["ns_forward_mel"])[0]
         rows.append([(d[0]-t0), (d[1]-d[0]), (wt[0]-d[1]), (wt[1]-wt[0]), (ml[0]-wt[1]), (ml[1]-ml[0]), (t1-ml[1]), (t2-t1), (t2-t0)])
 r = np.median(np.array(rows[5:]) * 1e6, axis=0)
 print("us: pre %.1f | C phase1 enqueue %.1f | to wait %.1f | wait %.1f | python after wait %.1f | C phase2 enqueue %.1f | return %.1f | final sync %.1f | total %.1f" % tuple(r))
