@@ -47,6 +47,7 @@ struct ns_model {
   std::vector<LayerW> enc, dec;
   PredW pred[3];
   size_t emb, enc_pos, dec_pos, pitch_bins, energy_bins, pitch_emb, energy_emb, mel_w, mel_b;
+  size_t pn_in, pn_hid, pn_const;  // derived at ns_finalize_weights: the PostNet over an all-padding utterance (packed rows, forward_mel)
   std::vector<PostW> post;
   Arena ar;
   float* arena = nullptr;
@@ -63,6 +64,7 @@ struct ns_model {
 };
 
 static const char* kPredNames[3] = {"duration", "pitch", "energy"};
+constexpr int PN_CONST_ROWS = 32;  // synthetic all-padding utterance: rows [10, 22) are deep padding, [22, 32) see the end of the axis
 
 static void expect(ns_model* m, const std::string& name, std::vector<int64_t> shape, bool optional = false) {
   Staged s; s.shape = std::move(shape); s.optional = optional; m->staged[name] = std::move(s);
@@ -174,6 +176,11 @@ extern "C" int ns_create(const ns_config* cfg, ns_model** out) {
     w.w_b3 = (c.matmul_bf16x3 && cin == c.postnet_dim && cout == c.postnet_dim) ? m->ar.take(((size_t)3 * cout * c.postnet_k * cin + 1) / 2) : NO_B3;
     m->post.push_back(w);
   }
+  // PostNet constants for packed rows (forward_mel): input, ping-pong scratch and output of one PostNet run over
+  // PN_CONST_ROWS all-padding frames; part of the arena so that they travel with the weights (ns_adopt_arena)
+  m->pn_in = m->ar.take((size_t)PN_CONST_ROWS * c.n_mel);
+  m->pn_hid = m->ar.take((size_t)2 * PN_CONST_ROWS * c.postnet_dim);
+  m->pn_const = m->ar.take((size_t)PN_CONST_ROWS * c.n_mel);
   *out = m;
   return 0;
 }
@@ -267,6 +274,7 @@ static void host_sinusoid(int n_pos, int d, float* dst) {  // transformer/Models
     }
 }
 
+static int postnet_constants(ns_model* m, hipStream_t st);  // (below, next to postnet())
 extern "C" int ns_finalize_weights(ns_model* m, void* stream) {
   if (!m) return fail("ns_finalize_weights: null model");
   if (!m->arena) return fail("ns_finalize_weights: bind an arena first (ns_bind_arena)");
@@ -350,6 +358,7 @@ extern "C" int ns_finalize_weights(ns_model* m, void* stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   NS_HIP(hipMemcpyAsync(m->arena, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  NS_TRY(postnet_constants(m, st));
   NS_HIP(hipStreamSynchronize(st));  // img is a local; also makes load_state_dict() synchronous like the reference's
   for (auto& kv : m->staged) { kv.second.data.clear(); kv.second.data.shrink_to_fit(); }
   m->ready = true;
@@ -633,6 +642,20 @@ static int postnet(const ns_model* m, const float* mel, int B, int T, const floa
   return 0;
 }
 
+// PostNet constants for packed rows (rowops.hip k_unpack_outputs): the PostNet over an all-padding utterance — every input
+// frame is the mel_linear bias (mel_linear of a zeroed decoder row, fastspeech2_align.py:83), zero padding at both ends of a
+// 32-frame axis.  Frame 21 of the result is deep padding (its 10-frame reach sees neither end), frames 22..31 see the end of
+// the axis.  Run once per weight load, into the arena.
+static int postnet_constants(ns_model* m, hipStream_t st) {
+  const ns_config& c = m->cfg;
+  float* in = m->arena + m->pn_in;
+  NS_HIP(launch_broadcast_row(m->P(m->mel_b), in, PN_CONST_ROWS, c.n_mel, st));
+  Scratch sc;
+  memset(&sc, 0, sizeof(sc));
+  sc.hid = m->arena + m->pn_hid;
+  return postnet(m, in, 1, PN_CONST_ROWS, in, m->arena + m->pn_const, sc, st);
+}
+
 static int encoder(const ns_model* m, const long long* texts, const long long* lens, int B, int L, float* out, Scratch& sc,
                    hipStream_t st) {
   const ns_config& c = m->cfg;
@@ -722,13 +745,11 @@ static size_t packed_rows(const int64_t* lens_host, int B, int T) {
   }
   return mp;
 }
-constexpr int PN_CONST_ROWS = 32;  // synthetic all-padding utterance: rows [10, 22) are deep padding, [22, 32) see the end of the axis
 static size_t packed_extra_bytes(const ns_config& c, int B, int T) {  // on top of carve(): plan, packed outputs, PostNet constants
   Bump bp(nullptr, 0);
   const size_t M = (size_t)B * T;
   bp.raw(pack_plan_ints(B, M) * sizeof(int));
   bp.f(M * c.n_mel); bp.f(M * c.n_mel); bp.f(M); bp.f(M); bp.f(M); bp.f(M);
-  bp.f((size_t)PN_CONST_ROWS * c.n_mel); bp.f((size_t)PN_CONST_ROWS * c.n_mel);
   return bp.off;
 }
 
@@ -771,13 +792,12 @@ static int forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens
 
   PackedCtx pk;
   memset(&pk, 0, sizeof(pk));
-  float *mel_p = nullptr, *post_p = nullptr, *pp_p = nullptr, *ep_p = nullptr, *pn_in = nullptr, *pn_out = nullptr;
+  float *mel_p = nullptr, *post_p = nullptr, *pp_p = nullptr, *ep_p = nullptr;
   if (packed) {
     int* plan = (int*)bp.raw(pack_plan_ints(B, Mp) * sizeof(int));
     mel_p = bp.f(Mp * c.n_mel); post_p = bp.f(Mp * c.n_mel); pp_p = bp.f(Mp); ep_p = bp.f(Mp);
     float* pt_p = bp.f(Mp);
     float* et_p = bp.f(Mp);
-    pn_in = bp.f((size_t)PN_CONST_ROWS * c.n_mel); pn_out = bp.f((size_t)PN_CONST_ROWS * c.n_mel);
     if (bp.off > ws_bytes) return fail("ns_forward_mel_packed: workspace too small");
     pk.Mp = M;
     NS_HIP(launch_length_regulate_packed(enc_out, cum, B, L, c.d_enc, T, M, c.n_dec_head, sc.xa, lens, status, sc.tickets, TICKET_INTS, plan, &pk.rm, st));
@@ -786,10 +806,6 @@ static int forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens
       if (l > T) l = T;
       pk.rm.att_wgs += (int)((l + 127) / 128) * c.n_dec_head;
     }
-    // PostNet constants (rowops.hip k_unpack_outputs): the PostNet over an all-padding utterance — every input frame is the
-    // mel_linear bias, zero padding at both ends of a 32-frame axis; frame 21 is deep padding, frames 22..31 see the end
-    NS_HIP(launch_broadcast_row(m->P(m->mel_b), pn_in, PN_CONST_ROWS, c.n_mel, st));
-    NS_TRY(postnet(m, pn_in, 1, PN_CONST_ROWS, pn_in, pn_out, sc, st));  // (dense: the packed scope opens below)
     // frame-level targets arrive on the padded [B, T] grid
     if (p_targets && c.pitch_frame_level) { NS_HIP(launch_pack_vector(pk.rm, T, p_targets, pt_p, M, st)); p_targets = pt_p; }
     if (e_targets && c.energy_frame_level) { NS_HIP(launch_pack_vector(pk.rm, T, e_targets, et_p, M, st)); e_targets = et_p; }
@@ -837,7 +853,7 @@ static int forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens
   m->prof_active = false;
   if (!rc && packed) {
     hipError_t e = launch_unpack_outputs(pk.rm, B, T, c.n_mel, lens, mel_p, post_p, c.pitch_frame_level ? pp_p : nullptr,
-                                         c.energy_frame_level ? ep_p : nullptr, m->P(m->mel_b), pn_out + (size_t)21 * c.n_mel, mel, postnet_mel,
+                                         c.energy_frame_level ? ep_p : nullptr, m->P(m->mel_b), m->P(m->pn_const) + (size_t)21 * c.n_mel, mel, postnet_mel,
                                          c.pitch_frame_level ? p_pred : nullptr, c.energy_frame_level ? e_pred : nullptr, mel_mask, st);
     if (e != hipSuccess) rc = fail(std::string("launch_unpack_outputs: ") + hipGetErrorString(e));
   }

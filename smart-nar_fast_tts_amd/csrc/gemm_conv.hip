@@ -132,9 +132,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
     const int m = m0 + r;
     int t = -1, sw = p.S;  // position of the row in its utterance and that utterance's window (packed rows: kernels.h RowMap)
     if (m < p.M) {
-      const int mg = m + p.m_base;  // (row of the full problem when this launch covers a row range of it)
-      if (p.rm.row_t) { t = p.rm.row_t[mg]; sw = p.rm.row_w[mg]; }
-      else t = mg % p.S;
+      if (p.rm.row_t) { t = p.rm.row_t[m]; sw = p.rm.row_w[m]; }
+      else t = m % p.S;
     }
     a_base[i] = (r * p.ldx + (ls ^ ((r >> FSH) & FMSK)) * 4) * 4;
     const int jlo = max(0, p.pad - t), jhi = min(p.KW, sw + p.pad - t);
@@ -417,24 +416,9 @@ bool conv_gemm_row_epilogue_ok(int M, int N, int Cin) {
   return M > 0 && (N == 256 || N == 512) && Cin % 32 == 0;
 }
 
-// rows [begin, begin + count) of p as a launch of its own (plain epilogue: the row-indexed operands are X, Y, resid)
-static ConvGemm row_range(const ConvGemm& p, int begin, int count) {
-  ConvGemm q = p;
-  q.X += (size_t)begin * p.ldx;
-  q.Y += (size_t)begin * p.ldy;
-  if (q.resid) q.resid += (size_t)begin * p.ldr;
-  q.M = count;
-  q.m_base = p.m_base + begin;
-  return q;
-}
-
-static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bool allow_split);
-hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) { return launch_conv_gemm_impl(p, st, true); }
-
-static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bool allow_split) {
+hipError_t launch_conv_gemm(const ConvGemm& p_in, hipStream_t st) {
   ConvGemm p = p_in;
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
-  if (p.m_base != 0 && p.epi != EPI_NONE) return hipErrorInvalidValue;
   if (p.ldw == 0) p.ldw = p.KW * p.Cin;
   if (p.Cin % 16 != 0 || (p.ldx & 3) != 0 || (p.ldw & 3) != 0 || p.ldw < p.KW * p.Cin) return hipErrorInvalidValue;
   if ((p.N & 3) != 0 || (p.ldy & 3) != 0 || (p.resid && (p.ldr & 3) != 0)) return hipErrorInvalidValue;  // float4 epilogues
@@ -476,6 +460,11 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
     if (rows64 >= 512) return launch_t<64, 96, 32, 1, 2, 3>(p, st);
     if (rows32 >= 400) return launch_t<32, 96, 32, 4, 1, 3>(p, st);
   }
+  // Mid-size row counts on the long-K convolutions (FFN k=9, PostNet k=5): a few utterances, or a packed variable-length
+  // batch.  Between the small-grid ladder's 512 workgroups and the point where whole rounds of the 64-row tiles average out,
+  // the 32x128 tile with two K groups keeps winning (tools/lab/gemm_lab_rem.hip, us: k9 256->1024 M = 2158 125 vs 151 (64x128),
+  // 3000 134 vs 160, 4100 204 vs 220, 4771 214 vs 226, then 6000 261 vs 236; k5 512->512 M = 4100 136 vs 164, 4771 139 vs 167,
+  // 6000 145 vs 171, then 7296 190 vs 177): its workgroups are half the size, so the partial last round costs half as much.
   // short contraction, wide output (the QKV projection: K = d, N = 3d): 8-16 K steps per tile, so prologue and epilogue weigh
   // as much as the loop and three 64x128 workgroups per CU interleave them better than two 64x256 ones.  Measured in the
   // FORWARD (alternating same-box runs; the lab loop had it the other way round at config 5): config 2 5.476 -> 5.456 ms,
@@ -492,33 +481,6 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
     const long c256 = wgs((p.M + 255) / 256, 256), c128 = wgs((p.M + 127) / 128, 256);
     if (c256 >= 200 && c256 <= 512 && fill(c256) >= 0.95) return launch_t<256, 256, 32, 1, 8, 2>(p, st);  // measured for one and two rounds only
     if (c128 <= 512 && fill(c128) >= 0.95) return launch_t<128, 256, 32, 1, 4, 4>(p, st);
-    // Row counts that fill none of these rounds (packed variable-length batches: M is whatever the utterances add up to)
-    // and are too few for the many-round 64x256 form to average the partial last round away: cut the rows into FULL rounds
-    // of the tall one-workgroup-per-CU tiles and hand the remainder to the rules below as a launch of its own (rows are
-    // independent; a convolution's taps reach across the cut through the operand pointers, ConvGemm::m_base keeps the
-    // utterance positions).  E.g. M = 10 200, N = 1024: 640 tiles of 64x256 on 512 slots (the second round a quarter full)
-    // becomes one full round of 128x256 (8192 rows) + 2008 rows on the small-grid ladder.
-    const long ntn = (p.N + 255) / 256, per = 256 / ntn;  // row tiles of one 256-workgroup round
-    if (allow_split && p.epi == EPI_NONE && per >= 1 && wgs(rows64, 256) < 4 * 512) {
-      int begin = 0;
-      long rem = p.M;
-      const long r256 = 256 * per, r128 = 128 * per;
-      long n = rem / r256;
-      if (n > 2) n = 2;
-      if (n >= 1) {
-        const hipError_t e = launch_t<256, 256, 32, 1, 8, 2>(row_range(p, begin, (int)(n * r256)), st);
-        if (e != hipSuccess) return e;
-        begin += (int)(n * r256); rem -= n * r256;
-      }
-      n = rem / r128;
-      if (n > 2) n = 2;
-      if (n >= 1) {
-        const hipError_t e = launch_t<128, 256, 32, 1, 4, 4>(row_range(p, begin, (int)(n * r128)), st);
-        if (e != hipSuccess) return e;
-        begin += (int)(n * r128); rem -= n * r128;
-      }
-      if (begin > 0) return rem > 0 ? launch_conv_gemm_impl(row_range(p, begin, (int)rem), st, false) : hipSuccess;
-    }
   }
   if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400) return launch_t<64, 256, 32, 1, 2, 4>(p, st);
   if (bk32 && p.N >= 128 && wgs(rows64, 128) > 256) return launch_t<64, 128, 32, 1, 2, 4>(p, st);

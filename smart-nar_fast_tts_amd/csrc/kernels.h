@@ -56,9 +56,6 @@ struct ConvGemm {
   const float* resid; int ldr;  // [M, N] or nullptr
   float* Y; int ldy;
   int M, N, Cin, KW, pad, S;
-  int m_base;                   // rows of the full matrix ahead of X / Y / resid row 0 (a launch over a row range of a larger
-                                // problem, gemm_conv.hip split plan): the utterance position of row m is that of row m_base + m.
-                                // Plain epilogues only (epi == EPI_NONE).
   int act;
   int epi;                      // RowEpi; != EPI_NONE requires conv_gemm_row_epilogue_ok(p)
   RowEpilogue e;

@@ -337,6 +337,9 @@ WORKLOADS = {
     # config 5 names "Gaussian-upsample": the same batch with the reference's (unwired) GaussianUpsampling module as
     # the length regulator — the extension of SURVEY.md §8 f1; the plain cfg5_longform is the reference's real path
     "cfg5_longform_gaussian": ("ljspeech+gaussian", 8, 128, 31.0),
+    # not a BASELINE config: a handful of utterances (B*T ~ 4000 rows), the size between the single-utterance and the
+    # chip-filling regime; used for tile-rule A/Bs (tools/ab_forward.sh) only
+    "mid_b4": ("ljspeech", 4, 128, 8.0),
 }
 
 
