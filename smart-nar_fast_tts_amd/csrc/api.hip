@@ -789,6 +789,21 @@ static int forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens
   m->last_rows = (long long)Mrows;
   Bump bp(ws_dec, ws_bytes);
   Scratch sc = carve(c, bp, Mrows, T, packed);
+  if (packed) {  // split-key partials for a work list of few workgroups (attention.hip packed launch): whatever the workspace still holds
+    size_t base = 0;
+    for (int b = 0; b < B; ++b) {
+      long long l = (lens_host[b] < 0 ? 0 : lens_host[b]) + PACK_GUARD;
+      base += (size_t)(((l < T ? l : T) + 127) / 128) * c.n_dec_head;
+    }
+    if (base < (size_t)ATT_SPLIT_MAX_BLOCKS * 2) {
+      const size_t per = Mrows * d + 2 * Mrows * c.n_dec_head;  // floats per key range
+      size_t n = (512 + base - 1) / base;
+      if (n > (size_t)ATT_SPLIT_MAX) n = ATT_SPLIT_MAX;
+      const size_t avail = ws_bytes > bp.off + packed_extra_bytes(c, B, T) ? (ws_bytes - bp.off - packed_extra_bytes(c, B, T)) / sizeof(float) : 0;
+      while (n > 1 && n * per > avail) --n;
+      if (n > 1) { sc.att_part_floats = n * per; sc.att_part = bp.f(sc.att_part_floats); }
+    }
+  }
 
   PackedCtx pk;
   memset(&pk, 0, sizeof(pk));
@@ -800,6 +815,7 @@ static int forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens
     float* et_p = bp.f(Mp);
     if (bp.off > ws_bytes) return fail("ns_forward_mel_packed: workspace too small");
     pk.Mp = M;
+    pk.rm.rows = M;
     NS_HIP(launch_length_regulate_packed(enc_out, cum, B, L, c.d_enc, T, M, c.n_dec_head, sc.xa, lens, status, sc.tickets, TICKET_INTS, plan, &pk.rm, st));
     for (int b = 0; b < B; ++b) {  // the attention work list's length, from the same lengths the device plan reads
       long long l = (lens_host[b] < 0 ? 0 : lens_host[b]) + PACK_GUARD;

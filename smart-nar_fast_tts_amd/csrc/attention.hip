@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
                                                     int S_grid, int d, float c_scale, float* __restrict__ out, int nsplit,
                                                     float* __restrict__ opart, float* __restrict__ mlpart,
                                                     const int* __restrict__ pk_off, const int* __restrict__ pk_win,
-                                                    const int* __restrict__ att_off, const int* __restrict__ att_order, int nutt) {
+                                                    const int* __restrict__ att_off, const int* __restrict__ att_order, int nutt,
+                                                    int pk_rows, int pk_heads) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BC = 32;                    // keys per tile
   constexpr int CPR = DK / 4;               // 16-B chunks per tile row
@@ -71,13 +72,15 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     int lo = 0, hi = nutt - 1;
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
-      if (att_off[mid] <= i) lo = mid;
+      if (att_off[mid] <= i / nsplit) lo = mid;
       else hi = mid - 1;
     }
     b = att_order[lo];
-    const int local = i - att_off[lo], qtiles = (pk_win[b] + 127) / 128;
+    // (with a key split every (head, query tile) appears nsplit times: att_off counts unsplit workgroups, the launch has
+    //  nsplit times as many and workgroup i is split i % nsplit of unsplit workgroup i / nsplit)
+    const int local = i / nsplit - att_off[lo], qtiles = (pk_win[b] + 127) / 128;
     hd = local / qtiles;
-    bx = local - hd * qtiles;
+    bx = (local - hd * qtiles) * nsplit + i % nsplit;
   } else {
     const int nx = gridDim.x, ny = gridDim.y, nblk = nx * ny * gridDim.z;
     const int L = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
@@ -284,7 +287,8 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   if (opart) {  // split-key mode: un-normalised partial for the merge kernel
     if (q < S) {
-      const size_t row = (size_t)sp * gridDim.z * S + (size_t)b * S + q;
+      const size_t row = pk_off ? (size_t)sp * pk_rows + row0 + q : (size_t)sp * gridDim.z * S + (size_t)b * S + q;
+      const int nheads = pk_off ? pk_heads : (int)gridDim.y;
       float* dst = opart + row * d + hd * DK + 4 * h;
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -296,8 +300,8 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
           *reinterpret_cast<f32x4*>(dst + 8 * NDB * u + 8 * pj) = v;
         }
       if (h == 0) {
-        mlpart[(row * gridDim.y + hd) * 2] = m_run;
-        mlpart[(row * gridDim.y + hd) * 2 + 1] = l_tot;
+        mlpart[(row * nheads + hd) * 2] = m_run;
+        mlpart[(row * nheads + hd) * 2 + 1] = l_tot;
       }
     }
     return;
@@ -623,17 +627,34 @@ __global__ __launch_bounds__(256) void k_attention_merge(const float* __restrict
 hipError_t launch_attention(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, float* scratch,
                             size_t scratch_floats, int* tickets, hipStream_t st, const RowMap* rm) {
   if (B <= 0 || S <= 0) return hipSuccess;
-  if (rm) {  // packed rows: one workgroup per (128-query tile of the longest window, head, utterance), no split-key path
+  if (rm) {  // packed rows: one workgroup per (128-query tile, head) of every utterance's window, longest utterances first
     const int d = H * dk;
     if ((long long)S * 3 * d * 4 >= (1ll << 31) || (dk != 128 && dk != 64 && dk != 32) || !rm->off || !rm->win) return hipErrorInvalidValue;
+    if (!rm->att_off || !rm->att_order || rm->att_wgs <= 0 || rm->rows <= 0) return hipErrorInvalidValue;
     const float c = 1.4426950408889634f / sqrtf((float)dk);
-    if (!rm->att_off || !rm->att_order || rm->att_wgs <= 0) return hipErrorInvalidValue;
-    dim3 grid(rm->att_wgs), block(256);
-#define NS_PK rm->off, rm->win, rm->att_off, rm->att_order, B
-    if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out, 1, nullptr, nullptr, NS_PK);
-    else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out, 1, nullptr, nullptr, NS_PK);
-    else hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, 1, nullptr, nullptr, NS_PK);
+    // Few workgroups (a handful of ragged utterances): the launch would last as long as the longest utterance's sweep while
+    // most CUs idle.  Every workgroup's key axis is cut into nsplit ranges (of ITS utterance's key tiles), the partials are
+    // merged by k_attention_merge — the split-key path of the grid, on the work list.
+    const size_t Mp = (size_t)rm->rows;
+    int nsplit = 1;
+    if (scratch && rm->att_wgs < ATT_SPLIT_MAX_BLOCKS * 2) {
+      nsplit = (512 + rm->att_wgs - 1) / rm->att_wgs;
+      if (nsplit > ATT_SPLIT_MAX) nsplit = ATT_SPLIT_MAX;
+      const int tiles = (S + 31) / 32;
+      if (nsplit > tiles) nsplit = tiles;
+      while (nsplit > 1 && (size_t)nsplit * (Mp * d + 2 * Mp * H) > scratch_floats) --nsplit;
+      if (nsplit < 1) nsplit = 1;
+    }
+    float* opart = nsplit > 1 ? scratch : nullptr;
+    float* mlpart = nsplit > 1 ? scratch + (size_t)nsplit * Mp * d : nullptr;
+    dim3 grid(rm->att_wgs * nsplit), block(256);
+#define NS_PK rm->off, rm->win, rm->att_off, rm->att_order, B, (int)Mp, H
+    if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, NS_PK);
+    else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, NS_PK);
+    else hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, NS_PK);
 #undef NS_PK
+    if (nsplit > 1)
+      hipLaunchKernelGGL(k_attention_merge, dim3((unsigned)((Mp + 3) / 4)), dim3(256), 0, st, opart, mlpart, (int)Mp, d, H, dk, nsplit, out);
     return hipGetLastError();
   }
   const int d = H * dk;
@@ -685,9 +706,9 @@ hipError_t launch_attention(const float* qkv, const long long* lens, int B, int 
   float* opart = nsplit > 1 ? scratch : nullptr;
   float* mlpart = nsplit > 1 ? scratch + (size_t)nsplit * M * d : nullptr;
   dim3 grid(qtiles * nsplit, H, B), block(256);
-  if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr, nullptr, nullptr, 0);
-  else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr, nullptr, nullptr, 0);
-  else hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr, nullptr, nullptr, 0);
+  if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr, nullptr, nullptr, 0, 0, 0);
+  else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr, nullptr, nullptr, 0, 0, 0);
+  else hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr, nullptr, nullptr, 0, 0, 0);
   if (nsplit > 1)
     hipLaunchKernelGGL(k_attention_merge, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, opart, mlpart, (int)M, d, H, dk, nsplit, out);
   return hipGetLastError();

@@ -132,8 +132,9 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
     const int m = m0 + r;
     int t = -1, sw = p.S;  // position of the row in its utterance and that utterance's window (packed rows: kernels.h RowMap)
     if (m < p.M) {
-      if (p.rm.row_t) { t = p.rm.row_t[m]; sw = p.rm.row_w[m]; }
-      else t = m % p.S;
+      const int mg = m + p.m_base;  // (row of the full problem when this launch covers a row range of it)
+      if (p.rm.row_t) { t = p.rm.row_t[mg]; sw = p.rm.row_w[mg]; }
+      else t = mg % p.S;
     }
     a_base[i] = (r * p.ldx + (ls ^ ((r >> FSH) & FMSK)) * 4) * 4;
     const int jlo = max(0, p.pad - t), jhi = min(p.KW, sw + p.pad - t);
@@ -416,9 +417,24 @@ bool conv_gemm_row_epilogue_ok(int M, int N, int Cin) {
   return M > 0 && (N == 256 || N == 512) && Cin % 32 == 0;
 }
 
-hipError_t launch_conv_gemm(const ConvGemm& p_in, hipStream_t st) {
+// rows [begin, begin + count) of p as a launch of its own (plain epilogue: the row-indexed operands are X, Y, resid)
+static ConvGemm row_range(const ConvGemm& p, int begin, int count) {
+  ConvGemm q = p;
+  q.X += (size_t)begin * p.ldx;
+  q.Y += (size_t)begin * p.ldy;
+  if (q.resid) q.resid += (size_t)begin * p.ldr;
+  q.M = count;
+  q.m_base = p.m_base + begin;
+  return q;
+}
+
+static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bool allow_split);
+hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) { return launch_conv_gemm_impl(p, st, true); }
+
+static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bool allow_split) {
   ConvGemm p = p_in;
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
+  if (p.m_base != 0 && p.epi != EPI_NONE) return hipErrorInvalidValue;
   if (p.ldw == 0) p.ldw = p.KW * p.Cin;
   if (p.Cin % 16 != 0 || (p.ldx & 3) != 0 || (p.ldw & 3) != 0 || p.ldw < p.KW * p.Cin) return hipErrorInvalidValue;
   if ((p.N & 3) != 0 || (p.ldy & 3) != 0 || (p.resid && (p.ldr & 3) != 0)) return hipErrorInvalidValue;  // float4 epilogues
@@ -481,6 +497,22 @@ hipError_t launch_conv_gemm(const ConvGemm& p_in, hipStream_t st) {
     const long c256 = wgs((p.M + 255) / 256, 256), c128 = wgs((p.M + 127) / 128, 256);
     if (c256 >= 200 && c256 <= 512 && fill(c256) >= 0.95) return launch_t<256, 256, 32, 1, 8, 2>(p, st);  // measured for one and two rounds only
     if (c128 <= 512 && fill(c128) >= 0.95) return launch_t<128, 256, 32, 1, 4, 4>(p, st);
+    // A row count somewhat above one or two FULL rounds of the 256x256 tile (packed variable-length batches: M is whatever
+    // the utterances add up to; a uniform batch of one utterance more than a round holds) and too small for the many-round
+    // 64x256 form to average its partial last round away: the full rounds go to the tall tile at its single-round rate, the
+    // remaining rows to the rules below as a launch of their own (rows are independent; a convolution's taps reach across the
+    // cut through the operand pointers, ConvGemm::m_base keeps the utterance positions).  Long-form ragged batch, M = 21 155,
+    // k=9 GEMM: 825 us as 1324 tiles of 64x256, 761 us as one round of 256x256 (16 384 rows) + 4771 rows of 64x128.
+    // (Cutting at rounds of the 128x256 tile was measured too and loses to the single launch: M = 10 350 468 vs 413 us,
+    // tools/lab/gemm_lab_rem.hip.)
+    const long ntn = (p.N + 255) / 256, per = 256 / ntn;  // row tiles of one 256-workgroup round
+    if (allow_split && p.epi == EPI_NONE && per >= 1 && p.M > 256 * per && wgs(rows64, 256) < 4 * 512) {
+      const long r256 = 256 * per;
+      const long n = p.M / r256 > 2 ? 2 : p.M / r256;
+      const hipError_t e = launch_t<256, 256, 32, 1, 8, 2>(row_range(p, 0, (int)(n * r256)), st);
+      if (e != hipSuccess) return e;
+      return launch_conv_gemm_impl(row_range(p, (int)(n * r256), (int)(p.M - n * r256)), st, false);
+    }
   }
   if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400) return launch_t<64, 256, 32, 1, 2, 4>(p, st);
   if (bk32 && p.N >= 128 && wgs(rows64, 128) > 256) return launch_t<64, 128, 32, 1, 2, 4>(p, st);

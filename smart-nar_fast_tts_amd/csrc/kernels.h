@@ -19,6 +19,7 @@ struct RowMap {
   // the hardware hands workgroups to CUs in launch order, so the launch finishes when the work does, not when the XCD that drew
   // the longest utterance does.
   const int* att_off; const int* att_order; int att_wgs;
+  int rows;                                              // M (host side)
 };
 
 // Row epilogue of a FULL-ROW tile (N == the tile width, 256 or 512): what the reference applies to every output row right
@@ -56,6 +57,9 @@ struct ConvGemm {
   const float* resid; int ldr;  // [M, N] or nullptr
   float* Y; int ldy;
   int M, N, Cin, KW, pad, S;
+  int m_base;                   // rows of the full matrix ahead of X / Y / resid row 0 (a launch over a row range of a larger
+                                // problem, gemm_conv.hip split plan): the utterance position of row m is that of row m_base + m.
+                                // Plain epilogues only (epi == EPI_NONE).
   int act;
   int epi;                      // RowEpi; != EPI_NONE requires conv_gemm_row_epilogue_ok(p)
   RowEpilogue e;
