@@ -24,6 +24,15 @@ for WL in cfg2_b16 cfg1_single cfg4_d512 cfg5_longform cfg5_longform_gaussian; d
   rocprofv3 --kernel-trace --stats --output-format rocpd csv -d "$OUT/$TAG" -o t -- $BENCH > "$OUT/$TAG.log" 2>&1
   grep '^{' "$OUT/$TAG.log" | tail -1 > "$OUT/${TAG/_trace/_bench_under_trace}.json"
 done
+# variable-length batches: phase 2 on packed rows (include/nar_fs2.h ns_forward_mel_packed) and, for comparison, on the padded grid
+for WL in cfg2_b16 cfg5_longform; do
+  for MODE in packed grid; do
+    TAG=${R}_trace_${WL}_ragged_${MODE}
+    PK=1; [ "$MODE" = grid ] && PK=0
+    NS_PACKED=$PK rocprofv3 --kernel-trace --stats --output-format rocpd csv -d "$OUT/$TAG" -o t -- python $ROOT/bench.py --workload $WL --ragged --steps 5 --warmup 2 --no-extras > "$OUT/$TAG.log" 2>&1
+    grep '^{' "$OUT/$TAG.log" | tail -1 > "$OUT/${TAG/_trace/_bench_under_trace}.json"
+  done
+done
 # rocprofv3's own per-kernel summary of the config-2 run, as it wrote it
 find "$OUT/${R}_trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/${R}_rocprofv3_kernel_stats.csv" \;
 

@@ -115,7 +115,8 @@ if lp:
 json.dump({"bench": bench, "bench_under_kernel_trace": under}, open(f"profiles/{ROUND}_bench.json", "w"), indent=1)
 
 # the other BASELINE configs (kernel trace only) and the opt-in bf16x3 mode
-for wl in ("cfg1_single", "cfg4_d512", "cfg5_longform", "cfg5_longform_gaussian", "bf16x3"):
+for wl in ("cfg1_single", "cfg4_d512", "cfg5_longform", "cfg5_longform_gaussian", "bf16x3",
+           "cfg2_b16_ragged_packed", "cfg2_b16_ragged_grid", "cfg5_longform_ragged_packed", "cfg5_longform_ragged_grid"):
     db = f"{G}/{ROUND}_trace_{wl}/t_results.db"
     if not os.path.exists(db):
         continue
