@@ -283,3 +283,35 @@ def test_default_init_state_dict_follows_torch_initialisers():
     assert (a["txt_encoder.src_word_emb.weight"][0] == 0).all() and abs(a["txt_encoder.src_word_emb.weight"][1:].std() - 1) < 0.05
     assert (a["postnet.convolutions.2.1.running_var"] == 1).all() and (a["postnet.convolutions.2.1.running_mean"] == 0).all()
     assert (a["variance_adaptor.pitch_predictor.conv_layer.layer_norm_1.weight"] == 1).all()
+
+
+def test_output_blocks_are_one_allocation_with_aligned_views():
+    """model._OutputBlock: forward() makes ONE allocation per phase and cuts the caller's tensors out of it; phase 2's block
+    is allocated at a guessed capacity and laid out again for the actual T (which must fit)."""
+    import torch
+
+    from smart_nar_fast_tts_amd.model import _OutputBlock
+
+    f32, u8, i64 = torch.float32, torch.bool, torch.long
+
+    def specs(B, T):
+        return [("mel", (B, T, 80), f32), ("post", (B, T, 80), f32), ("mel_masks", (B, T), u8), ("p_pred", (B, T), f32), ("lens", (B,), i64)]
+
+    blk = _OutputBlock(specs(3, 40), "cpu")
+    cap = blk.nbytes
+    base = blk.buf.data_ptr()
+    blk.layout(specs(3, 33))  # the actual T turned out smaller than the capacity
+    assert blk.nbytes <= cap
+    seen = []
+    for name, shape, dtype in specs(3, 33):
+        v = blk.view(name)
+        assert tuple(v.shape) == shape and v.dtype == dtype and v.is_contiguous()
+        off = v.data_ptr() - base
+        assert off % 256 == 0 and off == blk.ptr(name).value - base and off + v.numel() * v.element_size() <= cap
+        seen.append((off, off + v.numel() * v.element_size()))
+    seen.sort()
+    assert all(a[1] <= b[0] for a, b in zip(seen, seen[1:])), "views overlap"
+    blk.view("mel").fill_(1.0)
+    blk.view("post").fill_(2.0)
+    assert float(blk.view("mel").sum()) == 3 * 33 * 80 and float(blk.view("post").sum()) == 2 * 3 * 33 * 80  # (no aliasing)
+    assert blk.ptr("absent").value in (None, 0)
