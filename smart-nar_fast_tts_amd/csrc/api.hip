@@ -777,9 +777,9 @@ static int forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens
   const float* dur_keep = be.f((size_t)B * L);
   const long long* lens = (const long long*)mel_lens;
   const int d = c.d_dec;
-  // packed rows: the hard regulator on the exact fp32 path, and only when the windows are a real saving over the grid
+  // packed rows: the exact fp32 path, and only when the windows are a real saving over the grid
   size_t Mp = 0;
-  bool packed = lens_host && c.length_regulator == 0 && !c.matmul_bf16x3 && !m->dec.empty();
+  bool packed = lens_host && !c.matmul_bf16x3 && !m->dec.empty();
   if (packed) {
     Mp = packed_rows(lens_host, B, T);
     packed = Mp > 0 && Mp < ((size_t)1 << 30) && Mp * 10 <= (size_t)B * T * 9;
@@ -816,7 +816,13 @@ static int forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens
     if (bp.off > ws_bytes) return fail("ns_forward_mel_packed: workspace too small");
     pk.Mp = M;
     pk.rm.rows = M;
-    NS_HIP(launch_length_regulate_packed(enc_out, cum, B, L, c.d_enc, T, M, c.n_dec_head, sc.xa, lens, status, sc.tickets, TICKET_INTS, plan, &pk.rm, st));
+    if (c.length_regulator == 1) {  // extension: GaussianUpsampling in the LengthRegulator's place, on the packed rows
+      if ((size_t)B * (L + 1) > (size_t)M * c.vp_filter) return fail("ns_forward_mel: workspace too small for the Gaussian centres");
+      NS_HIP(launch_pack_plan(lens, B, T, c.n_dec_head, M, plan, &pk.rm, st));
+      NS_HIP(launch_gaussian_upsampling(enc_out, dur_keep, B, L, c.d_enc, T, T, sc.xa, sc.vp2, nullptr, lens, status, sc.tickets, TICKET_INTS, st, &pk.rm));
+    } else {
+      NS_HIP(launch_length_regulate_packed(enc_out, cum, B, L, c.d_enc, T, M, c.n_dec_head, sc.xa, lens, status, sc.tickets, TICKET_INTS, plan, &pk.rm, st));
+    }
     for (int b = 0; b < B; ++b) {  // the attention work list's length, from the same lengths the device plan reads
       long long l = (lens_host[b] < 0 ? 0 : lens_host[b]) + PACK_GUARD;
       if (l > T) l = T;

@@ -132,12 +132,14 @@ hipError_t launch_length_regulate_packed(const float* x, const int32_t* cum, int
 // dst[r, :] = row[:] for r < rows (n % 4 == 0)
 hipError_t launch_broadcast_row(const float* row, float* dst, int rows, int n, hipStream_t st);
 hipError_t launch_pack_vector(const RowMap& rm, int T, const float* src, float* dst, int Mp, hipStream_t st);
+// the packing plan and row maps alone (launch_length_regulate_packed builds them as a side effect of its gather)
+hipError_t launch_pack_plan(const long long* mel_lens, int B, int T, int H, int Mp, int* plan, RowMap* rm, hipStream_t st);
 // padded outputs from packed rows (api.hip forward_mel): see k_unpack_outputs in rowops.hip
 hipError_t launch_unpack_outputs(const RowMap& rm, int B, int T, int n_mel, const long long* mel_lens, const float* mel_p, const float* post_p,
                                  const float* p_p, const float* e_p, const float* mel_bias, const float* post_const, float* mel,
                                  float* post, float* p_pred, float* e_pred, uint8_t* mel_mask, hipStream_t st);
 hipError_t launch_gaussian_upsampling(const float* x, const float* dur, int B, int L, int D, int T, int T_out,
                                       float* out, float* s, float* w, const long long* own_len, int32_t* status, int* zero, int nzero,
-                                      hipStream_t st);
+                                      hipStream_t st, const RowMap* rm = nullptr);  // rm: out is the packed layout (w must be nullptr)
 
 }  // namespace ns

@@ -379,6 +379,40 @@ __global__ __launch_bounds__(256) void k_pack_plan(const long long* __restrict__
   }
 }
 
+// the row maps alone (the Gaussian regulator's packed form gathers nothing: it computes its rows in place)
+__global__ void k_pack_rows(const int* __restrict__ off, const int* __restrict__ win, int B, int Mp, int* __restrict__ row_b,
+                            int* __restrict__ row_t, int* __restrict__ row_w) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= Mp) return;
+  int lo = 0, hi = B - 1;  // largest b with off[b] <= m
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (off[mid] <= m) lo = mid;
+    else hi = mid - 1;
+  }
+  row_b[m] = lo; row_t[m] = m - off[lo]; row_w[m] = win[lo];
+}
+
+static void plan_pointers(int* plan, int B, int Mp, RowMap* rm) {
+  int* off = plan;
+  int* win = off + B + 1;
+  int* att_off = win + B + 1;
+  int* att_order = att_off + B + 1;
+  int* row_b = att_order + B + 1;
+  rm->off = off; rm->win = win; rm->att_off = att_off; rm->att_order = att_order;
+  rm->row_b = row_b; rm->row_t = row_b + Mp; rm->row_w = row_b + 2 * (size_t)Mp;
+}
+
+hipError_t launch_pack_plan(const long long* mel_lens, int B, int T, int H, int Mp, int* plan, RowMap* rm, hipStream_t st) {
+  if (B <= 0 || Mp <= 0 || !plan || !rm || !mel_lens) return hipErrorInvalidValue;
+  plan_pointers(plan, B, Mp, rm);
+  hipLaunchKernelGGL(k_pack_plan, dim3(1), dim3(256), 0, st, mel_lens, B, T, H, const_cast<int*>(rm->off), const_cast<int*>(rm->win),
+                     const_cast<int*>(rm->att_off), const_cast<int*>(rm->att_order));
+  hipLaunchKernelGGL(k_pack_rows, dim3((Mp + 255) / 256), dim3(256), 0, st, rm->off, rm->win, B, Mp, const_cast<int*>(rm->row_b),
+                     const_cast<int*>(rm->row_t), const_cast<int*>(rm->row_w));
+  return hipGetLastError();
+}
+
 // LengthRegulator.LR + pad (model/modules.py:201-218) into the packed layout: row m belongs to the utterance b with
 // off[b] <= m < off[b+1] (binary search), frame t = m - off[b]; also writes the row maps every later kernel reads.
 __global__ __launch_bounds__(256) void k_length_regulate_packed(const float* __restrict__ x, const int32_t* __restrict__ cum, int B, int L,
@@ -421,18 +455,13 @@ hipError_t launch_length_regulate_packed(const float* x, const int32_t* cum, int
                                          const long long* mel_lens, int32_t* status, int* zero, int nzero, int* plan, RowMap* rm,
                                          hipStream_t st) {
   if (B <= 0 || Mp <= 0 || D % 4 != 0 || !plan || !rm || !mel_lens) return hipErrorInvalidValue;
-  int* off = plan;
-  int* win = off + B + 1;
-  int* att_off = win + B + 1;
-  int* att_order = att_off + B + 1;
-  int* row_b = att_order + B + 1;
-  int* row_t = row_b + Mp;
-  int* row_w = row_t + Mp;
-  hipLaunchKernelGGL(k_pack_plan, dim3(1), dim3(256), 0, st, mel_lens, B, T, H, off, win, att_off, att_order);
-  rm->att_off = att_off; rm->att_order = att_order;  // (att_wgs: the caller's, from its host copy of the lengths)
+  plan_pointers(plan, B, Mp, rm);
+  int* off = const_cast<int*>(rm->off);
+  int* win = const_cast<int*>(rm->win);
+  hipLaunchKernelGGL(k_pack_plan, dim3(1), dim3(256), 0, st, mel_lens, B, T, H, off, win, const_cast<int*>(rm->att_off),
+                     const_cast<int*>(rm->att_order));  // (att_wgs, rows: the caller's, from its host copy of the lengths)
   hipLaunchKernelGGL(k_length_regulate_packed, dim3((Mp + 3) / 4), dim3(256), 0, st, x, cum, B, L, D, T, Mp, out, mel_lens, status, off, win,
-                     row_b, row_t, row_w, zero, nzero);
-  rm->off = off; rm->win = win; rm->row_b = row_b; rm->row_t = row_t; rm->row_w = row_w;
+                     const_cast<int*>(rm->row_b), const_cast<int*>(rm->row_t), const_cast<int*>(rm->row_w), zero, nzero);
   return hipGetLastError();
 }
 
@@ -540,12 +569,17 @@ __global__ __launch_bounds__(256) void k_gauss_centers(const float* __restrict__
 typedef float f32x16r __attribute__((ext_vector_type(16)));
 constexpr int GU_LC = 256;
 __global__ __launch_bounds__(256) void k_gauss_upsample(const float* __restrict__ x, const float* __restrict__ centers, int L,
-                                                         int D, int T, int T_out, float* __restrict__ out,
-                                                         float* __restrict__ w, const long long* __restrict__ own_len) {
+                                                         int D, int T, int T_out_grid, float* __restrict__ out,
+                                                         float* __restrict__ w, const long long* __restrict__ own_len,
+                                                         const int* __restrict__ pk_off, const int* __restrict__ pk_win) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the MFMA builtin does not exist in the host pass; it only needs the stub
   __shared__ float wt[32 * (GU_LC + 1)];
   __shared__ float w2s[32];
   const int b = blockIdx.y, t0 = blockIdx.x * 32, tid = threadIdx.x, lane = tid & 63;
+  // packed rows (kernels.h RowMap): utterance b's frames are rows [pk_off[b], pk_off[b] + pk_win[b]) of `out`
+  const int T_out = pk_win ? pk_win[b] : T_out_grid;
+  const size_t row0 = pk_off ? (size_t)pk_off[b] : (size_t)b * T_out_grid;
+  if (t0 >= T_out) return;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tt = tid & 31, sub = tid >> 5;  // frame of this thread inside the tile, and which eighth of the phonemes it walks
   const float* cb = centers + (size_t)b * L;
@@ -609,7 +643,7 @@ __global__ __launch_bounds__(256) void k_gauss_upsample(const float* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (t < T_out && tile * 32 + (lane & 31) < D) out[((size_t)b * T_out + t) * D + tile * 32 + (lane & 31)] = t < t_lim ? acc[j][r] : 0.f;
+        if (t < T_out && tile * 32 + (lane & 31) < D) out[(row0 + t) * D + tile * 32 + (lane & 31)] = t < t_lim ? acc[j][r] : 0.f;
       }
     }
   }
@@ -617,12 +651,14 @@ __global__ __launch_bounds__(256) void k_gauss_upsample(const float* __restrict_
 }
 hipError_t launch_gaussian_upsampling(const float* x, const float* dur, int B, int L, int D, int T, int T_out, float* out,
                                       float* s, float* w, const long long* own_len, int32_t* status, int* zero, int nzero,
-                                      hipStream_t st) {
+                                      hipStream_t st, const RowMap* rm) {
   if (B <= 0 || T_out <= 0) return hipSuccess;
+  if (rm && w) return hipErrorInvalidValue;  // (the weight tensor is a [B, L, T] grid output of the stand-alone module)
   // s holds B sums followed by B*L Gaussian centres (scratch)
   float* centers = s + B;
   hipLaunchKernelGGL(k_gauss_centers, dim3(B), dim3(64), 0, st, dur, L, centers, s, own_len, T, status, zero, nzero);
-  hipLaunchKernelGGL(k_gauss_upsample, dim3((T_out + 31) / 32, B), dim3(256), 0, st, x, centers, L, D, T, T_out, out, w, own_len);
+  hipLaunchKernelGGL(k_gauss_upsample, dim3((T_out + 31) / 32, B), dim3(256), 0, st, x, centers, L, D, T, T_out, out, w, own_len,
+                     rm ? rm->off : nullptr, rm ? rm->win : nullptr);
   return hipGetLastError();
 }
 

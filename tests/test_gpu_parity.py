@@ -802,14 +802,18 @@ def test_packed_rows_match_the_dense_grid_on_ragged_batches():
     import smart_nar_fast_tts_amd.workload as wl
     from smart_nar_fast_tts_amd.model import FastSpeech2Align
 
-    cases = [("ljspeech", 8.0, np.array([128, 10, 64, 1, 100, 33, 127, 17, 128, 5, 77, 2]), 128),
-             ("ljspeech", 31.0, np.array([128, 16, 90, 40, 128, 61, 20, 110]), 128),   # long-form: T_pad ~ 3900
-             ("ljspeech", 3.0, np.array([60, 5, 20, 2, 40]), 60),                       # windows of a few dozen frames
-             ("d512", 8.0, np.array([100, 30, 128, 64, 12, 90]), 128)]
-    for cfg_name, fpp, lens, L in cases:
+    cases = [("ljspeech", 8.0, np.array([128, 10, 64, 1, 100, 33, 127, 17, 128, 5, 77, 2]), 128, {}),
+             ("ljspeech", 31.0, np.array([128, 16, 90, 40, 128, 61, 20, 110]), 128, {}),   # long-form: T_pad ~ 3900
+             ("ljspeech", 3.0, np.array([60, 5, 20, 2, 40]), 60, {}),                       # windows of a few dozen frames
+             ("d512", 8.0, np.array([100, 30, 128, 64, 12, 90]), 128, {}),
+             # BASELINE config 5 as worded: Gaussian upsampling AND variable lengths (the regulator writes into the windows)
+             ("ljspeech", 31.0, np.array([128, 16, 90, 40, 128, 61, 20, 110]), 128, {"length_regulator": "gaussian"}),
+             ("ljspeech", 8.0, np.array([100, 7, 64, 1, 33]), 100, {"length_regulator": "gaussian"})]
+    for cfg_name, fpp, lens, L, extra in cases:
         _MODEL.clear()
         meta = dict(config=cfg_name, weight_seed=0, frames_per_phoneme=fpp, dur_weight_scale=0.25)
         cfg, sd = weights_for(meta)
+        cfg = dict(cfg, **extra)
         inp = wl.synth_inputs(len(lens), L, seed=9, src_lens=lens)
         args = (dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3])
         models = {}
@@ -837,7 +841,7 @@ def test_packed_rows_match_the_dense_grid_on_ragged_batches():
             assert packed[i].shape == dense[i].shape
             worst[NAMES[i]] = float((packed[i] - dense[i]).abs().max())
             assert torch.isfinite(packed[i]).all()
-        print("packed vs dense", cfg_name, "fpp", fpp, "rows", rows_packed, "of", rows_dense, worst)
+        print("packed vs dense", cfg_name, extra, "fpp", fpp, "rows", rows_packed, "of", rows_dense, worst)
         assert worst["output"] < 2e-5 and worst["postnet_output"] < 2e-5 and worst["e_predictions"] < 2e-4, worst
         # with targets the prediction itself is returned: pitch does not depend on the targets, energy on the pitch bucket only
         assert worst["p_predictions"] < 2e-3 * max(1.0, float(dense[2].abs().max())), worst
