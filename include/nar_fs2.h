@@ -124,7 +124,7 @@ int ns_forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens, fl
  * utterance's end computed, all others constants of the weights (the PostNet has no mask between its layers).
  * mel_lens_host: the caller's HOST copy of mel_lens (what ns_forward_durations wrote to its mel_lens_host): the row count of
  * the launches comes from it, so this is the synchronous path's entry point.  The call falls back to the dense grid by
- * itself when packing does not apply (bf16x3 mode) or saves less than 10 % of the rows. */
+ * itself when packing does not apply (bf16x3 mode) or saves less than 10 % of the rows (20 % on grids of up to 20 000 rows, where the grid is one full round of the tallest tile). */
 int ns_forward_mel_packed(ns_model* m, int B, int L, int T, const int64_t* mel_lens, const int64_t* mel_lens_host,
                           float p_control, float e_control, const float* p_targets, const float* e_targets, const void* ws_enc,
                           void* ws_dec, size_t ws_dec_bytes, float* mel, float* postnet_mel, float* p_pred, float* e_pred,

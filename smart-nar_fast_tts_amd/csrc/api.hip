@@ -782,7 +782,11 @@ static int forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens
   bool packed = lens_host && !c.matmul_bf16x3 && !m->dec.empty();
   if (packed) {
     Mp = packed_rows(lens_host, B, T);
-    packed = Mp > 0 && Mp < ((size_t)1 << 30) && Mp * 10 <= (size_t)B * T * 9;
+    // measured, packed against grid over length distributions (profiles/r03_packed_vs_grid_by_padding.txt): any saving of 10 %
+    // pays on grids of 30 000 rows and more (0.89 of the rows: 1.07x, 0.85: 1.06-1.12x); a grid of ~16 000 rows is ONE full round
+    // of the 256x256 tile, the packed rows fill no round, and the break-even is at 0.80 of the rows (0.80: 1.005x, 0.88: 0.99x)
+    const size_t grid_rows = (size_t)B * T;
+    packed = Mp > 0 && Mp < ((size_t)1 << 30) && Mp * 10 <= grid_rows * (grid_rows <= 20000 ? 8 : 9);
   }
   const size_t Mrows = packed ? Mp : (size_t)B * T;
   const int M = (int)Mrows;
