@@ -27,7 +27,7 @@ void run(const ConvGemm& p, double gf) {
 
 int main() {
   struct Shape { const char* name; int Cin, KW, N; } shapes[] = {{"k9 256->1024", 256, 9, 1024}, {"k5 512->512 ", 512, 5, 512}};
-  const int Ms[] = {700, 1400, 2158, 3000, 4100, 4771, 6000, 7296, 10350};
+  const int Ms[] = {10240, 10350, 12288, 12800, 14000, 14336, 16160};
   for (auto& s : shapes)
     for (int M : Ms) {
       size_t nx = (size_t)M * s.Cin, nw = (size_t)s.N * s.KW * s.Cin, ny = (size_t)M * s.N;
@@ -51,12 +51,13 @@ int main() {
       CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
       float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 20;
       printf("   launch_conv_gemm's own plan              %8.1f us  %6.1f TF/s\n", ms * 1e3, gf / ms);
-      run<32, 128, 32, 2, 1, 4>(p, gf);
+      run<160, 256, 32, 1, 5, 2>(p, gf);
+      run<192, 256, 32, 1, 6, 2>(p, gf);
+      run<224, 256, 32, 1, 7, 2>(p, gf);
       run<64, 128, 32, 1, 2, 4>(p, gf);
       run<64, 256, 32, 1, 2, 4>(p, gf);
       run<128, 256, 32, 1, 4, 4>(p, gf);
       run<256, 256, 32, 1, 8, 2>(p, gf);
-      run<32, 64, 32, 4, 1, 2>(p, gf);
       CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(db)); CK(hipFree(dy));
     }
   return 0;
