@@ -478,6 +478,8 @@ class FastSpeech2Align:
                     if T < longest:
                         raise ValueError(f"max_mel_len() returned {T}, smaller than the longest utterance ({longest})")
                 else:
+                    if len(self._t_hint) > 4096:  # (a server sees many batch shapes: keep the table small)
+                        self._t_hint.clear()
                     self._t_hint[(B, L)] = T
                 if blk2 is not None and T > Tc:
                     blk2 = ws_dec = None
