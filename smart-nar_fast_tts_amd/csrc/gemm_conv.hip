@@ -514,7 +514,15 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
       return launch_conv_gemm_impl(row_range(p, (int)(n * r256), (int)(p.M - n * r256)), st, false);
     }
   }
-  if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400) return launch_t<64, 256, 32, 1, 2, 4>(p, st);
+  if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400) {
+    // Few rounds (a batch of ~10 utterances, a packed variable-length batch): a launch's time is a staircase in units of 256
+    // workgroups, one per CU — 64x256 137 us per step of 256 tiles, 64x128 73.6 us (k=9 256->1024; tools/lab/gemm_lab_tall.hip) —
+    // so when the half-size tile needs fewer than 2 x 0.93 as many steps it wins by up to a step of the big one
+    // (M = 10 240: 368 vs 413 us).  Beyond eight steps the partial last step no longer matters and the wider tile's rate does.
+    const long sc = (wgs(rows64, 256) + 255) / 256, sd = (wgs(rows64, 128) + 255) / 256;
+    if (sc <= 8 && p.N % 128 == 0 && (double)sd * 0.5 < 0.93 * (double)sc) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
+    return launch_t<64, 256, 32, 1, 2, 4>(p, st);
+  }
   if (bk32 && p.N >= 128 && wgs(rows64, 128) > 256) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
   // Fewer output tiles than that (encoder-side GEMMs, single-utterance latency): a workgroup's time is set by how fast
   // ONE CU can pull its operand panels, (BM + BN) * K * 4 bytes, through LDS-DMA, so what matters is to put every CU to

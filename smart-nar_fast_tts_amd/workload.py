@@ -340,6 +340,7 @@ WORKLOADS = {
     # not a BASELINE config: a handful of utterances (B*T ~ 4000 rows), the size between the single-utterance and the
     # chip-filling regime; used for tile-rule A/Bs (tools/ab_forward.sh) only
     "mid_b4": ("ljspeech", 4, 128, 8.0),
+    "mid_b10": ("ljspeech", 10, 128, 8.0),
 }
 
 
