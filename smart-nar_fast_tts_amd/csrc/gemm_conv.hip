@@ -524,6 +524,10 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
     return launch_t<64, 256, 32, 1, 2, 4>(p, st);
   }
   if (bk32 && p.N >= 128 && wgs(rows64, 128) > 256) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
+  // The remainder of a split plan stays on tiles WITHOUT an in-workgroup K split: every such tile sums a row's contraction in
+  // the same order, so the rows behind the cut carry the same bits as the rows ahead of it (replicas of one utterance inside
+  // a batch stay bit-identical wherever the cut falls); the K-split ladder below rounds differently.
+  if (!allow_split && bk32 && p.N >= 128) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
   // Fewer output tiles than that (encoder-side GEMMs, single-utterance latency): a workgroup's time is set by how fast
   // ONE CU can pull its operand panels, (BM + BN) * K * 4 bytes, through LDS-DMA, so what matters is to put every CU to
   // work — the smallest tile that still yields <= 256 workgroups (one round, one per CU) — and to spend the rest of the

@@ -764,6 +764,17 @@ def test_large_batch_replicas_are_identical():
     for i in (0, 1):
         err = (big[i][:16] - small_p[i]).abs().cpu().numpy()[valid].max()
         assert err < 2e-5, (NAMES[i], err)
+    # 17 and 21 copies of ONE utterance: B*T_pad is a little more than one full round of the 256x256 tile, so the k=9 GEMM is
+    # cut into that round + a remainder launch (gemm_conv.hip split plan) — the copies behind the cut must carry the same bits
+    T1 = int(small[9][0])  # the copies' own length is their T_pad
+    for R1 in (17, 21):
+        with torch.no_grad():
+            one = m(dev(np.tile(sp[:1], R1)), dev(np.tile(tx[:1], (R1, 1))), dev(np.tile(ln[:1], R1)), L,
+                    p_targets=small[2][:1, :T1].repeat(R1, 1), e_targets=small[3][:1, :T1].repeat(R1, 1))
+        assert R1 * T1 > 16384 and one[0].shape[1] == T1
+        torch.cuda.synchronize()
+        for i in (0, 1, 2, 3, 4, 5, 9):
+            assert all(torch.equal(one[i][r], one[i][0]) for r in range(1, R1)), (NAMES[i], R1, "copies differ across the split")
 
 
 def test_ragged_batch_vs_oracle():
