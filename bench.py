@@ -78,6 +78,7 @@ def main():
                     help="profiling runs: only warm-up + timed steps (no latency leg, no pipelined leg, no CPU baseline), so that a "
                          "kernel trace holds exactly (warmup + steps) forwards of the workload")
     ap.add_argument("--ragged", action="store_true", help="ragged utterance lengths instead of the uniform BASELINE batch (phase 2 then runs on packed rows; NS_PACKED=0 keeps the padded grid)")
+    ap.add_argument("--batch", type=int, default=0, help="override the workload's per-GPU batch size (sweeps; not a BASELINE config)")
     ap.add_argument("--streams", type=int, default=1, help="issue consecutive steps round-robin on this many HIP streams")
     ap.add_argument("--global-pad", action="store_true", help="pad every shard to the global max mel length (all-reduce MAX)")
     ap.add_argument("--matmul", choices=["fp32", "bf16x3"], default="fp32",
@@ -120,6 +121,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
 
     cfg_name, B_shard, L, fpp = wl.WORKLOADS[args.workload]
+    if args.batch > 0:
+        B_shard = args.batch
     cfg = wl.model_config(cfg_name)
     b3 = args.matmul == "bf16x3"
     if b3:
@@ -248,7 +251,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16x3" if b3 else "f32", "data": "synthetic",
         "devices": devices, "backend": backend, "world_size_seen_by_rccl": world_seen, "one_gpu_rig": one_gpu, "per_rank": per_rank,
-        "config": {"workload": f"{args.workload}{'_bf16x3' if b3 else ''}{' (ragged lengths)' if args.ragged else ''}: LJSpeech config, batch {B_shard}/GPU x {args.gpus} GPU, phoneme_len {L}, "
+        "config": {"workload": f"{args.workload}{'_bf16x3' if b3 else ''}{' (ragged lengths)' if args.ragged else ''}{f' (batch overridden: {args.batch})' if args.batch > 0 else ''}: LJSpeech config, batch {B_shard}/GPU x {args.gpus} GPU, phoneme_len {L}, "
                                f"T_pad {T_pad_max}, d_model {cfg['transformer']['decoder_hidden']}, "
                                f"{cfg['transformer']['encoder_layer']}+{cfg['transformer']['decoder_layer']} FFT layers, "
                                f"random-init weights (seed 0, duration bias log({fpp + 1:g}))",
