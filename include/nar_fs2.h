@@ -10,6 +10,13 @@
  * in a caller-provided arena and every call takes a caller-provided workspace
  * (PyTorch is only the allocator / stream owner on the Python side).
  *
+ * THREADING.  One ns_model serves ONE host thread at a time: the forward keeps per-call state (the packed-row context,
+ * the measurement slots, the row count of the last forward) in the model / in thread-local storage while it enqueues its
+ * launches.  Calls on the same model from two host threads must be serialised by the caller; different models (one per
+ * thread, or one per process as bench.py does per GPU) are independent, and one thread may drive several HIP streams
+ * with one model as long as each stream has its own workspaces.  ns_last_error() is per thread.  This matches the
+ * reference's caller: single-threaded, synchronous, one module instance (synthesize.py:59-76).
+ *
  * All tensors are dense row-major float32 unless stated; token ids and lengths
  * are int64 (what torch.long hands over); masks are uint8 with 1 = padding
  * (utils/tools.py:89-97: True = padding).
@@ -49,6 +56,11 @@ typedef struct ns_config {
                                enough to fill the chip with 64..256-row tiles, smaller ones stay fp32) run from an exact
                                3-way bf16 split of both operands on the bf16 matrix cores, 6 products, fp32 accumulation:
                                fp32-sized error, different bits, ~1.8x faster on those layers (csrc/gemm_bf16x3.hip) */
+  int32_t row_epilogue;     /* 0 = the default: on small grids LayerNorm / the predictor tail / attention's key-range merge run as
+                               TICKETED last-arriver epilogues inside the producing launch (csrc/gemm_conv.hip TICKET,
+                               csrc/attention.hip); 1 = "two_launch": the same row functions as separate launches, no ticket is
+                               ever drawn.  Same bits either way — the switch exists so that tests can A/B the ticket protocol
+                               (tests/test_gpu_stress.py).  The full-row tile of large launches needs no ticket and is not affected */
 } ns_config;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -183,7 +195,9 @@ int ns_op_attention_core(const float* qkv, const int64_t* lens, int B, int S, in
                          size_t scratch_bytes, void* stream);
 
 /* Measurement hook for bench.py's roofline legs: while enabled, the launches of the three heaviest kernels inside
- * ns_forward_mel are bracketed by hipEvents on the launch stream, one slot each:
+ * ns_forward_mel carry hipEvents ON THEIR OWN DISPATCH PACKETS (hipExtLaunchKernel start / stop events: the kernel's begin and
+ * end timestamps, no marker packet on the stream; a timed launch still costs the stream ~5 us, so bench.py times slot 0 inside
+ * its timed region and the other two in a separate pass), one slot each:
  *   slot 0  the FFT blocks' k=9 Conv1D-as-GEMM (PositionwiseFeedForward.w_1, transformer/SubLayers.py:70-75; the dominant
  *           kernel): flops = 2*rows*k*d*d_inner per launch
  *   slot 1  the fused attention (transformer/Modules.py:14-25): flops = 4*rows*T*d per launch
@@ -191,6 +205,9 @@ int ns_op_attention_core(const float* qkv, const int64_t* lens, int B, int S, in
  * ns_profile_read_slot waits for the slot's events and returns the summed kernel time, the summed algorithmic flops and
  * the launch count, then resets the slot.  ns_profile_read is slot 0. */
 #define NS_PROFILE_SLOTS 3
+#define NS_PROFILE_OFF 0
+#define NS_PROFILE_ALL 1
+#define NS_PROFILE_SLOT(i) (2 << (i)) /* OR several together to time exactly those slots */
 int ns_profile_enable(ns_model* m, int on);
 int ns_profile_read(ns_model* m, double* total_ms, double* total_flops, int64_t* launches);
 int ns_profile_read_slot(ns_model* m, int slot, double* total_ms, double* total_flops, int64_t* launches);

@@ -21,7 +21,7 @@ class NsConfig(C.Structure):
         "n_vocab", "max_seq_len", "d_enc", "n_enc_layer", "n_enc_head", "d_dec", "n_dec_layer", "n_dec_head",
         "d_inner", "ffn_k1", "ffn_k2", "vp_filter", "vp_kernel", "n_bins", "n_mel",
         "postnet_dim", "postnet_k", "postnet_n", "pitch_frame_level", "energy_frame_level", "length_regulator",
-        "matmul_bf16x3")]
+        "matmul_bf16x3", "row_epilogue")]
 
 
 _P, _I, _F, _Z, _S = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_char_p

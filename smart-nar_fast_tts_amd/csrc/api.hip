@@ -46,6 +46,7 @@ struct ns_model {
   ns_config cfg;
   std::vector<LayerW> enc, dec;
   PredW pred[3];
+  size_t hdr;  // arena header: magic, layout version, arena size, config hash (arena_header below)
   size_t emb, enc_pos, dec_pos, pitch_bins, energy_bins, pitch_emb, energy_emb, mel_w, mel_b;
   size_t pn_in, pn_hid, pn_const;  // derived at ns_finalize_weights: the PostNet over an all-padding utterance (packed rows, forward_mel)
   std::vector<PostW> post;
@@ -59,11 +60,30 @@ struct ns_model {
   // Measurement state, not model state: mutable so that the (const) forward helpers can record into it.
   struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double flops = 0.0; };
   mutable long long last_rows = 0;  // rows phase 2 of the most recent ns_forward_mel[_packed] ran on (B*T, or the packed windows)
-  mutable bool prof = false, prof_active = false;
+  mutable unsigned prof = 0;  // bit i: slot i is timed (ns_profile_enable)
+  mutable bool prof_active = false;
   mutable ProfSlot prof_slot[NS_PROFILE_SLOTS];
 };
 
 static const char* kPredNames[3] = {"duration", "pitch", "energy"};
+
+// The arena is position independent and travels between processes as bytes (ns_adopt_arena after an RCCL broadcast, or a file).
+// Its first 64 bytes say what it is: a magic word, the LAYOUT VERSION of this library (bump it whenever an offset, a packing
+// rule or a derived constant in the arena changes), the arena size and a hash of the configuration — so that bytes packed by
+// another build, for another configuration, or never finalized are refused instead of silently misread.
+constexpr uint32_t ARENA_MAGIC = 0x3246534eu;  // "NSF2"
+constexpr uint32_t ARENA_LAYOUT_VERSION = 4;   // round 4: header added (round 3's layout 3 grew the PostNet constants)
+constexpr int ARENA_HDR_WORDS = 16;
+static void arena_header(const ns_model* m, uint32_t* w) {
+  memset(w, 0, ARENA_HDR_WORDS * sizeof(uint32_t));
+  uint64_t h = 1469598103934665603ull;  // FNV-1a over the config struct
+  const unsigned char* cb = reinterpret_cast<const unsigned char*>(&m->cfg);
+  for (size_t i = 0; i < sizeof(ns_config); ++i) { h ^= cb[i]; h *= 1099511628211ull; }
+  w[0] = ARENA_MAGIC; w[1] = ARENA_LAYOUT_VERSION;
+  w[2] = (uint32_t)(m->ar.n & 0xffffffffu); w[3] = (uint32_t)((uint64_t)m->ar.n >> 32);
+  w[4] = (uint32_t)(h & 0xffffffffu); w[5] = (uint32_t)(h >> 32);
+  w[6] = 1;  // finalized (postnet constants computed)
+}
 constexpr int PN_CONST_ROWS = 32;  // synthetic all-padding utterance: rows [10, 22) are deep padding, [22, 32) see the end of the axis
 
 static void expect(ns_model* m, const std::string& name, std::vector<int64_t> shape, bool optional = false) {
@@ -123,10 +143,12 @@ extern "C" int ns_create(const ns_config* cfg, ns_model** out) {
     return fail("ns_create: kernel sizes must be odd");
   if (c.length_regulator != 0 && c.length_regulator != 1) return fail("ns_create: length_regulator must be 0 (hard) or 1 (gaussian)");
   if (c.matmul_bf16x3 != 0 && c.matmul_bf16x3 != 1) return fail("ns_create: matmul_bf16x3 must be 0 (fp32) or 1 (bf16x3)");
+  if (c.row_epilogue != 0 && c.row_epilogue != 1) return fail("ns_create: row_epilogue must be 0 (fused) or 1 (two_launch)");
   if (c.vp_kernel != 3) return fail("ns_create: variance predictor conv1d_2 hard-codes padding=1 (model/modules.py:267); kernel_size must be 3");
   ns_model* m = new ns_model();
   m->cfg = c;
   const int d = c.d_enc, npos = c.max_seq_len + 1;
+  m->hdr = m->ar.take(ARENA_HDR_WORDS);
   expect(m, "txt_encoder.src_word_emb.weight", {c.n_vocab, d});
   expect(m, "txt_encoder.position_enc", {1, npos, d}, true);
   expect(m, "mel_decoder.position_enc", {1, npos, c.d_dec}, true);
@@ -204,6 +226,16 @@ extern "C" int ns_bind_arena(ns_model* m, void* dev, size_t bytes) {
 
 extern "C" int ns_adopt_arena(ns_model* m) {
   if (!m || !m->arena) return fail("ns_adopt_arena: no arena bound");
+  // the bytes may have arrived on any stream (an RCCL broadcast): wait for the device, then read the header back
+  uint32_t got[ARENA_HDR_WORDS], want[ARENA_HDR_WORDS];
+  NS_HIP(hipDeviceSynchronize());
+  NS_HIP(hipMemcpy(got, m->arena + m->hdr, sizeof(got), hipMemcpyDeviceToHost));
+  arena_header(m, want);
+  if (got[0] != ARENA_MAGIC) return fail("ns_adopt_arena: the arena does not start with this library's magic word (not a finalized ns_model arena)");
+  if (got[1] != want[1]) return fail("ns_adopt_arena: arena layout version " + std::to_string(got[1]) + ", this library packs version " + std::to_string(want[1]));
+  if (got[2] != want[2] || got[3] != want[3]) return fail("ns_adopt_arena: arena size differs from ns_arena_bytes of this model");
+  if (got[4] != want[4] || got[5] != want[5]) return fail("ns_adopt_arena: the arena was packed for a different ns_config");
+  if (got[6] != 1) return fail("ns_adopt_arena: the arena was not finalized (ns_finalize_weights did not complete)");
   for (auto& kv : m->staged) { kv.second.data.clear(); kv.second.data.shrink_to_fit(); kv.second.set = false; }
   m->ready = true;
   return 0;
@@ -287,6 +319,7 @@ extern "C" int ns_finalize_weights(ns_model* m, void* stream) {
   auto S = [&](const std::string& k) -> const std::vector<float>& { return m->staged[k].data; };
   auto cp = [&](size_t off, const std::string& k) { const auto& v = S(k); memcpy(&img[off], v.data(), v.size() * sizeof(float)); };
 
+  arena_header(m, reinterpret_cast<uint32_t*>(&img[m->hdr]));
   cp(m->emb, "txt_encoder.src_word_emb.weight");
   const int npos = c.max_seq_len + 1;
   if (m->staged["txt_encoder.position_enc"].set) cp(m->enc_pos, "txt_encoder.position_enc");
@@ -404,12 +437,19 @@ static Scratch carve(const ns_config& c, Bump& bp, size_t M, int S, bool no_spli
   s.vp1 = bp.f(M * c.vp_filter); s.vp2 = bp.f(M * c.vp_filter);
   s.pos_ext = S > c.max_seq_len ? bp.f((size_t)S * d) : nullptr;
   // attention's split-key partials: only launches with few workgroups take that path (kernels.h)
-  const int hmin = c.n_enc_head < c.n_dec_head ? c.n_enc_head : c.n_dec_head;
+  // attention's split-key partials: few workgroups (small grids), or a last round of 256 that fills badly (attention.hip
+  // plan_key_split) — as many key ranges as either stack's launch of this shape will ask for
   const int hmax = c.n_enc_head > c.n_dec_head ? c.n_enc_head : c.n_dec_head;
-  const size_t qtiles = ((size_t)S + 127) / 128;
-  s.att_part_floats = (!no_split && (M / (size_t)S) * qtiles * hmin < ATT_SPLIT_MAX_BLOCKS) ? ATT_SPLIT_MAX * (M * d + 2 * M * hmax) : 0;  // (packed rows never split)
+  int nsp = 1;
+  if (!no_split && S > 0) {  // (packed rows size their own split: forward_mel)
+    const int Bg = (int)(M / (size_t)S);
+    const int ne = attention_split(Bg, S, c.n_enc_head, c.d_enc / c.n_enc_head), nd = attention_split(Bg, S, c.n_dec_head, c.d_dec / c.n_dec_head);
+    nsp = ne > nd ? ne : nd;
+  }
+  s.att_part_floats = nsp > 1 ? (size_t)nsp * (M * d + 2 * M * hmax) : 0;
   s.att_part = s.att_part_floats ? bp.f(s.att_part_floats) : nullptr;
   s.tickets = (int*)bp.raw(TICKET_INTS * sizeof(int));
+  if (c.row_epilogue == 1) s.tickets = nullptr;  // "two_launch": take_tickets() then always answers "spent" (the block stays reserved)
   s.tickets_used = 0;
   return s;
 }
@@ -458,7 +498,7 @@ static int rows_of(int B, int S) { return tl_pk ? tl_pk->Mp : B * S; }
 
 static int gemm(const float* X, int ldx, const float* W, const float* bias, const float* resid, int ldr, float* Y, int ldy,
                 int M, int N, int Cin, int KW, int S, int act, hipStream_t st, const RowEpilogue* epi = nullptr, int epi_mode = EPI_NONE,
-                const unsigned short* Wb3 = nullptr) {
+                const unsigned short* Wb3 = nullptr, const LaunchTiming* tm = nullptr) {
   ConvGemm p;
   memset(&p, 0, sizeof(p));
   p.X = X; p.ldx = ldx; p.W = W; p.bias = bias; p.resid = resid; p.ldr = ldr; p.Y = Y; p.ldy = ldy;
@@ -469,10 +509,12 @@ static int gemm(const float* X, int ldx, const float* W, const float* bias, cons
   // opt-in bf16x3 planes exist for this weight AND the launch is large enough for the 128-row tiles: split-bf16 matrix cores
   if (Wb3 && conv_gemm_b3_ok(M, N, Cin, KW, p.epi)) {
     p.Wb3 = Wb3;
+    if (tm && tm->start) NS_HIP(hipEventRecord(tm->start, st));  // (the experiment mode keeps marker events around its launch)
     NS_HIP(launch_conv_gemm_b3(p, st));
+    if (tm && tm->stop) NS_HIP(hipEventRecord(tm->stop, st));
     return 0;
   }
-  NS_HIP(launch_conv_gemm(p, st));
+  NS_HIP(launch_conv_gemm(p, st, tm));
   return 0;
 }
 
@@ -499,7 +541,15 @@ static int gemm_ln(const float* X, int ldx, const float* W, const float* bias, c
     NS_HIP(launch_layernorm(tmp, g, b, Y, M, N, S, lens, st, cur_rm()));
     return 0;
   }
-  if (fuse_row_epilogue(M, N, Cin)) return gemm(X, ldx, W, bias, resid, N, Y, N, M, N, Cin, KW, S, act, st, &e, EPI_LN, Wb3);
+  if (fuse_row_epilogue(M, N, Cin)) {
+    // large launches: the full-row tile — unless its steps of 256 tiles fit the row count badly and 64x64 tiles with the
+    // ticketed epilogue are cheaper (the step-aware plan, gemm_conv.hip conv_gemm_ln_form; same bits either way)
+    if (!Wb3 && conv_gemm_ln_form(M, N, Cin, KW) == LN_TICKET && (e.ticket = sc.take_tickets(conv_gemm_ticket_ints(M))) != nullptr) {
+      e.y_out = Y;
+      return gemm(X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st, &e, EPI_LN);
+    }
+    return gemm(X, ldx, W, bias, resid, N, Y, N, M, N, Cin, KW, S, act, st, &e, EPI_LN, Wb3);
+  }
   if (conv_gemm_ticket_ok(M, N, Cin) && (e.ticket = sc.take_tickets(conv_gemm_ticket_ints(M))) != nullptr) {
     e.y_out = Y;
     return gemm(X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st, &e, EPI_LN);
@@ -509,12 +559,14 @@ static int gemm_ln(const float* X, int ldx, const float* W, const float* bias, c
   return 0;
 }
 
-// HIP-event bracket around one launch group on the launch stream; a no-op unless ns_profile_enable(1) and the
-// forward is inside its timed section (the decoder stack / PostNet of ns_forward_mel)
+// Timing of one launch group inside the real forward; a no-op unless ns_profile_enable(1) and the forward is inside its
+// timed section (the decoder stack / PostNet of ns_forward_mel).  The events ride on the group's own dispatch packets
+// (kernels.h LaunchTiming): no marker packet, no gap on the stream — marker pairs around the 11 timed launches of a forward
+// cost it ~130 us (3 % at config 2, round 3's bench line paid that inside its timed region).
 struct ProfScope {
-  const ns_model* m; int slot; hipStream_t st; double flops; bool on;
-  ProfScope(const ns_model* m_, int slot_, hipStream_t st_, double flops_)
-      : m(m_), slot(slot_), st(st_), flops(flops_), on(m_->prof_active) {}
+  const ns_model* m; int slot; double flops; bool on;
+  LaunchTiming tm{nullptr, nullptr};
+  ProfScope(const ns_model* m_, int slot_, double flops_) : m(m_), slot(slot_), flops(flops_), on(m_->prof_active && ((m_->prof >> slot_) & 1u)) {}
   int begin() {
     if (!on) return 0;
     ns_model::ProfSlot& ps = m->prof_slot[slot];
@@ -524,16 +576,15 @@ struct ProfScope {
       NS_HIP(hipEventCreate(&b));
       ps.ev.emplace_back(a, b);
     }
-    NS_HIP(hipEventRecord(ps.ev[ps.used].first, st));
+    tm = LaunchTiming{ps.ev[ps.used].first, ps.ev[ps.used].second};
     return 0;
   }
-  int end() {
-    if (!on) return 0;
+  const LaunchTiming* timing() const { return on ? &tm : nullptr; }
+  void end() {
+    if (!on) return;
     ns_model::ProfSlot& ps = m->prof_slot[slot];
-    NS_HIP(hipEventRecord(ps.ev[ps.used].second, st));
     ps.used++;
     ps.flops += flops;
-    return 0;
   }
 };
 
@@ -544,11 +595,11 @@ static int mha(const ns_model* m, const LayerW& L, int d, int H, const float* x,
   auto b3 = [&](size_t off) { return off != NO_B3 ? reinterpret_cast<const unsigned short*>(m->P(off)) : nullptr; };
   NS_TRY(gemm(x, d, m->P(L.qkv_w), m->P(L.qkv_b), nullptr, 0, sc.qkv, 3 * d, M, 3 * d, d, 1, S, ACT_NONE, st, nullptr, EPI_NONE, b3(L.qkv_b3)));
   {
-    ProfScope ps(m, 1, st, 4.0 * (double)M * (double)S * (double)d);
+    ProfScope ps(m, 1, 4.0 * (double)M * (double)S * (double)d);
     NS_TRY(ps.begin());
     NS_HIP(launch_attention(sc.qkv, lens, B, S, H, d / H, sc.att, sc.att_part, sc.att_part_floats,
-                            (sc.att_part && !tl_pk) ? sc.take_tickets(attention_ticket_ints(B, S, H)) : nullptr, st, cur_rm()));
-    NS_TRY(ps.end());
+                            (sc.att_part && !tl_pk) ? sc.take_tickets(attention_ticket_ints(B, S, H)) : nullptr, st, cur_rm(), ps.timing()));
+    ps.end();
   }
   return gemm_ln(sc.att, d, m->P(L.fc_w), m->P(L.fc_b), x, sc.t1, out, M, d, d, 1, S, ACT_NONE, m->P(L.ln1_g), m->P(L.ln1_b),
                  mask_rows ? lens : nullptr, sc, st, b3(L.fc_b3));
@@ -560,11 +611,11 @@ static int ffn(const ns_model* m, const LayerW& L, int d, const float* x, const 
   const ns_config& c = m->cfg;
   const int M = rows_of(B, S);
   {
-    ProfScope ps(m, 0, st, 2.0 * (double)M * (double)c.ffn_k1 * (double)d * (double)c.d_inner);
+    ProfScope ps(m, 0, 2.0 * (double)M * (double)c.ffn_k1 * (double)d * (double)c.d_inner);
     NS_TRY(ps.begin());
     NS_TRY(gemm(x, d, m->P(L.w1), m->P(L.w1_b), nullptr, 0, sc.hid, c.d_inner, M, c.d_inner, d, c.ffn_k1, S, ACT_RELU, st, nullptr, EPI_NONE,
-                L.w1_b3 != NO_B3 ? reinterpret_cast<const unsigned short*>(m->P(L.w1_b3)) : nullptr));
-    NS_TRY(ps.end());
+                L.w1_b3 != NO_B3 ? reinterpret_cast<const unsigned short*>(m->P(L.w1_b3)) : nullptr, ps.timing()));
+    ps.end();
   }
   return gemm_ln(sc.hid, c.d_inner, m->P(L.w2), m->P(L.w2_b), x, sc.t1, out, M, d, c.d_inner, c.ffn_k2, S, ACT_NONE, m->P(L.ln2_g),
                  m->P(L.ln2_b), mask_rows ? lens : nullptr, sc, st,
@@ -607,8 +658,11 @@ static int predictor(const ns_model* m, const PredW& w, const float* x, const lo
   e.ln_g = m->P(w.ln2_g); e.ln_b = m->P(w.ln2_b); e.lens = lens; e.wlin = m->P(w.lin_w); e.blin = m->P(w.lin_b); e.pred = pred;
   e.control = control; e.target = target; e.bins = bins; e.n_edges = c.n_bins - 1; e.emb = emb; e.x_in = x; e.pos = pos; e.x_out = x_out;
   e.D = w.cin;
-  if (fuse_row_epilogue(M, F, F))
+  if (fuse_row_epilogue(M, F, F)) {
+    if (conv_gemm_ln_form(M, F, F, c.vp_kernel) == LN_TICKET && (e.ticket = sc.take_tickets(conv_gemm_ticket_ints(M))) != nullptr)
+      return gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st, &e, EPI_LN_PRED);
     return gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, nullptr, F, M, F, F, c.vp_kernel, S, ACT_RELU, st, &e, EPI_LN_PRED);
+  }
   if (conv_gemm_ticket_ok(M, F, F) && (e.ticket = sc.take_tickets(conv_gemm_ticket_ints(M))) != nullptr)
     return gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st, &e, EPI_LN_PRED);
   NS_TRY(gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st));
@@ -630,12 +684,12 @@ static int postnet(const ns_model* m, const float* mel, int B, int T, const floa
     const bool last = i + 1 == m->post.size();
     float* dst = last ? out : ((i & 1) ? pong : ping);
     const bool mid = w.cin == c.postnet_dim && w.cout == c.postnet_dim;
-    ProfScope ps(m, 2, st, 2.0 * (double)M * (double)c.postnet_k * (double)w.cin * (double)w.cout);
+    ProfScope ps(m, 2, 2.0 * (double)M * (double)c.postnet_k * (double)w.cin * (double)w.cout);
     if (mid) NS_TRY(ps.begin());
     NS_TRY(gemm(cur, ld, m->P(w.w), m->P(w.b), last ? resid : nullptr, c.n_mel, dst, w.cout, M, w.cout, w.cin, c.postnet_k, T,
                 last ? ACT_NONE : ACT_TANH, st, nullptr, EPI_NONE,
-                w.w_b3 != NO_B3 ? reinterpret_cast<const unsigned short*>(m->P(w.w_b3)) : nullptr));
-    if (mid) NS_TRY(ps.end());
+                w.w_b3 != NO_B3 ? reinterpret_cast<const unsigned short*>(m->P(w.w_b3)) : nullptr, mid ? ps.timing() : nullptr));
+    if (mid) ps.end();
     cur = dst;
     ld = w.cout;
   }
@@ -799,10 +853,9 @@ static int forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens
       long long l = (lens_host[b] < 0 ? 0 : lens_host[b]) + PACK_GUARD;
       base += (size_t)(((l < T ? l : T) + 127) / 128) * c.n_dec_head;
     }
-    if (base < (size_t)ATT_SPLIT_MAX_BLOCKS * 2) {
+    size_t n = (size_t)attention_split_packed((int)base, T, d / c.n_dec_head, Mrows, d);
+    if (n > 1) {
       const size_t per = Mrows * d + 2 * Mrows * c.n_dec_head;  // floats per key range
-      size_t n = (512 + base - 1) / base;
-      if (n > (size_t)ATT_SPLIT_MAX) n = ATT_SPLIT_MAX;
       const size_t avail = ws_bytes > bp.off + packed_extra_bytes(c, B, T) ? (ws_bytes - bp.off - packed_extra_bytes(c, B, T)) / sizeof(float) : 0;
       while (n > 1 && n * per > avail) --n;
       if (n > 1) { sc.att_part_floats = n * per; sc.att_part = bp.f(sc.att_part_floats); }
@@ -871,7 +924,7 @@ static int forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens
     NS_HIP(launch_add_pos(cur, pos, alt, M, T, d, st, cur_rm()));
     float* t = cur; cur = alt; alt = t;
   }
-  m->prof_active = m->prof;  // time only phase 2's launches: one shape per slot (the encoder runs the same kernels at B*L rows)
+  m->prof_active = m->prof != 0;  // time only phase 2's launches: one shape per slot (the encoder runs the same kernels at B*L rows)
   int rc = decoder_stack(m, cur, lens, B, T, sc.att, sc, st);
   // note: decoder_stack's last layer writes into sc.att only after its own attention output was consumed
   if (!rc) rc = gemm(sc.att, d, m->P(m->mel_w), m->P(m->mel_b), nullptr, 0, mel_dst, c.n_mel, M, c.n_mel, d, 1, T, ACT_NONE, st);
@@ -930,7 +983,7 @@ static int find_layer(ns_model* m, const char* prefix_c, const LayerW** L, int* 
   hipStream_t st = (hipStream_t)stream;                                               \
   Bump bp(ws, ws_bytes);                                                              \
   Scratch sc = carve(m->cfg, bp, (size_t)(B_) * (S_), (S_));                          \
-  NS_HIP(hipMemsetAsync(sc.tickets, 0, TICKET_INTS * sizeof(int), st)); /* a forward's first kernel does this itself */
+  if (sc.tickets) NS_HIP(hipMemsetAsync(sc.tickets, 0, TICKET_INTS * sizeof(int), st)); /* a forward's first kernel does this itself */
 
 extern "C" int ns_op_mask_from_lengths(const int64_t* lens, int B, int max_len, uint8_t* mask, void* stream) {
   NS_HIP(launch_mask_from_lengths((const long long*)lens, B, max_len, mask, (hipStream_t)stream));
@@ -1001,7 +1054,7 @@ extern "C" int ns_op_variance_embedding(ns_model* m, int which, const float* x, 
 }
 extern "C" int ns_profile_enable(ns_model* m, int on) {
   if (!m) return fail("ns_profile_enable: null model");
-  m->prof = on != 0;
+  m->prof = on == 1 ? (1u << NS_PROFILE_SLOTS) - 1u : on < 0 ? 0u : ((unsigned)on >> 1);  // 1 = every slot; 2 * mask = those slots
   for (auto& ps : m->prof_slot) { ps.used = 0; ps.flops = 0.0; }
   return 0;
 }

@@ -24,6 +24,7 @@
 // are skipped; rows past S are zero-filled by the buffer descriptor's range check.  Padded QUERY rows are
 // computed like the reference does.  An utterance with lens[b] == 0 yields NaN rows (0 * inf), as the reference's
 // all -inf softmax does (SURVEY.md §8b "Errors").
+#include <hip/hip_ext.h>
 #include "kernels.h"
 
 namespace ns {
@@ -556,6 +557,7 @@ __global__ __launch_bounds__(256) void k_attention_strip(const float* __restrict
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{m_all, l_all}), rsML, mlrow(sp), 0, 16);
     }
   }
+  if (!tickets) return;  // two-launch form (no ticket block): k_attention_merge combines the same partials in the same order
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int* const last = reinterpret_cast<int*>(Vs);  // (the (m, l) words parked there were consumed before the barrier above)
@@ -624,9 +626,66 @@ __global__ __launch_bounds__(256) void k_attention_merge(const float* __restrict
   }
 }
 
+// Key split of a dense launch that fills the chip unevenly.  k_attention runs ONE workgroup per CU (4 waves, one per SIMD), so
+// a launch's time is ceil(workgroups / 256) sweeps of its key axis: 144 workgroups (B = 9) take as long as 256, 272 (B = 17)
+// twice as long.  Cutting every workgroup's key axis into n ranges gives n times the workgroups with 1/n of the sweep each,
+// and the rounds fill: measured (tools/lab/attn_lab_split.hip, us, S = 1010, d_k = 128) B = 9 141 -> 108 (n = 3), B = 12
+// 145 -> 124 (4), B = 17 266 -> 189 (5), B = 20 268 -> 196 (4), B = 24 272 -> 227 (2); B = 5 at S = 3900 959 -> 610 (4).
+// The model that reproduces every one of those: rounds * (3.7 + c * key tiles per range) + merge, c = 3.9 us per 32-key tile
+// at d_k = 128 (attn_fixed.hip), 2.1 at 64, 1.2 at 32; k_attention_merge ~4 us + its traffic.  n = 1 unless the split is
+// worth 6 %.  (Exact for any n: every range leaves an exact partial softmax, merged in key order.)
+static int plan_key_split(long blocks, int tiles, int dk, size_t M, int d) {
+  const float c = dk == 128 ? 3.9f : dk == 64 ? 2.1f : 1.2f, f = 3.7f;
+  auto rounds = [](long wgs) { return (float)((wgs + 255) / 256); };
+  const float one = rounds(blocks) * (f + c * (float)tiles);
+  int best = 1;
+  float best_us = one * 0.94f;
+  for (int n = 2; n <= ATT_SPLIT_MAX && n <= tiles; ++n) {
+    const int tps = (tiles + n - 1) / n;
+    if ((tiles + tps - 1) / tps != n) continue;  // (only splits without an empty range)
+    const float us = rounds(blocks * n) * (f + c * (float)tps) + 4.0f + (float)((double)(n + 1) * (double)M * d * 4.0 / 12e6);
+    if (us < best_us) { best = n; best_us = us; }
+  }
+  return best;
+}
+
+int attention_split(int B, int S, int H, int dk) {
+  if (B <= 0 || S <= 0) return 1;
+  const long blocks = (long)((S + 127) / 128) * H * B;
+  if (blocks < ATT_SPLIT_MAX_BLOCKS) return ATT_SPLIT_MAX;  // the small-grid paths below size their own split, up to this
+  if (!launch_planner_enabled()) return 1;
+  return plan_key_split(blocks, (S + 31) / 32, dk, (size_t)B * S, H * dk);
+}
+
+// packed rows: the work list of att_wgs (128-query tile, head) workgroups, longest utterance (S frames) first
+int attention_split_packed(int att_wgs, int S, int dk, size_t Mp, int d) {
+  if (att_wgs <= 0 || S <= 0) return 1;
+  const int tiles = (S + 31) / 32;
+  if (!launch_planner_enabled()) {
+    if (att_wgs >= ATT_SPLIT_MAX_BLOCKS * 2) return 1;
+    int n = (512 + att_wgs - 1) / att_wgs;
+    if (n > ATT_SPLIT_MAX) n = ATT_SPLIT_MAX;
+    return n > tiles ? tiles : n;
+  }
+  if (att_wgs < ATT_SPLIT_MAX_BLOCKS) {  // a handful of utterances: enough ranges for ~2 workgroups per CU
+    int n = (512 + att_wgs - 1) / att_wgs;
+    if (n > ATT_SPLIT_MAX) n = ATT_SPLIT_MAX;
+    return n > tiles ? tiles : n;
+  }
+  return plan_key_split(att_wgs, tiles, dk, Mp, d);
+}
+
+// k_attention with optional dispatch-attached timing events (kernels.h LaunchTiming)
+template <int DK, typename... Args>
+static void launch_k_attention(dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, Args... args) {
+  if (e0 || e1) hipExtLaunchKernelGGL((k_attention<DK>), grid, dim3(256), 0, st, e0, e1, 0, args...);
+  else hipLaunchKernelGGL((k_attention<DK>), grid, dim3(256), 0, st, args...);
+}
+
 hipError_t launch_attention(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, float* scratch,
-                            size_t scratch_floats, int* tickets, hipStream_t st, const RowMap* rm) {
+                            size_t scratch_floats, int* tickets, hipStream_t st, const RowMap* rm, const LaunchTiming* tm) {
   if (B <= 0 || S <= 0) return hipSuccess;
+  hipEvent_t ev0 = tm ? tm->start : nullptr, ev1 = tm ? tm->stop : nullptr;
   if (rm) {  // packed rows: one workgroup per (128-query tile, head) of every utterance's window, longest utterances first
     const int d = H * dk;
     if ((long long)S * 3 * d * 4 >= (1ll << 31) || (dk != 128 && dk != 64 && dk != 32) || !rm->off || !rm->win) return hipErrorInvalidValue;
@@ -637,24 +696,24 @@ hipError_t launch_attention(const float* qkv, const long long* lens, int B, int 
     // merged by k_attention_merge — the split-key path of the grid, on the work list.
     const size_t Mp = (size_t)rm->rows;
     int nsplit = 1;
-    if (scratch && rm->att_wgs < ATT_SPLIT_MAX_BLOCKS * 2) {
-      nsplit = (512 + rm->att_wgs - 1) / rm->att_wgs;
-      if (nsplit > ATT_SPLIT_MAX) nsplit = ATT_SPLIT_MAX;
-      const int tiles = (S + 31) / 32;
-      if (nsplit > tiles) nsplit = tiles;
+    if (scratch) {
+      nsplit = attention_split_packed(rm->att_wgs, S, dk, Mp, d);
       while (nsplit > 1 && (size_t)nsplit * (Mp * d + 2 * Mp * H) > scratch_floats) --nsplit;
       if (nsplit < 1) nsplit = 1;
     }
     float* opart = nsplit > 1 ? scratch : nullptr;
     float* mlpart = nsplit > 1 ? scratch + (size_t)nsplit * Mp * d : nullptr;
-    dim3 grid(rm->att_wgs * nsplit), block(256);
+    dim3 grid(rm->att_wgs * nsplit);
+    hipEvent_t k1 = nsplit > 1 ? nullptr : ev1;  // (with a merge launch the stop event rides on the merge)
 #define NS_PK rm->off, rm->win, rm->att_off, rm->att_order, B, (int)Mp, H
-    if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, NS_PK);
-    else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, NS_PK);
-    else hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, NS_PK);
+    if (dk == 128) launch_k_attention<128>(grid, st, ev0, k1, qkv, lens, S, d, c, out, nsplit, opart, mlpart, NS_PK);
+    else if (dk == 64) launch_k_attention<64>(grid, st, ev0, k1, qkv, lens, S, d, c, out, nsplit, opart, mlpart, NS_PK);
+    else launch_k_attention<32>(grid, st, ev0, k1, qkv, lens, S, d, c, out, nsplit, opart, mlpart, NS_PK);
 #undef NS_PK
-    if (nsplit > 1)
-      hipLaunchKernelGGL(k_attention_merge, dim3((unsigned)((Mp + 3) / 4)), dim3(256), 0, st, opart, mlpart, (int)Mp, d, H, dk, nsplit, out);
+    if (nsplit > 1) {
+      if (ev1) hipExtLaunchKernelGGL(k_attention_merge, dim3((unsigned)((Mp + 3) / 4)), dim3(256), 0, st, nullptr, ev1, 0, opart, mlpart, (int)Mp, d, H, dk, nsplit, out);
+      else hipLaunchKernelGGL(k_attention_merge, dim3((unsigned)((Mp + 3) / 4)), dim3(256), 0, st, opart, mlpart, (int)Mp, d, H, dk, nsplit, out);
+    }
     return hipGetLastError();
   }
   const int d = H * dk;
@@ -674,7 +733,7 @@ hipError_t launch_attention(const float* qkv, const long long* lens, int B, int 
     int nsplit = (int)((256 + strips - 1) / strips);
     if (nsplit > (tiles + 3) / 4) nsplit = (tiles + 3) / 4;   // at least one key tile per wave
     if (nsplit > ATT_STRIP_SPLIT_MAX) nsplit = ATT_STRIP_SPLIT_MAX;
-    if (nsplit > 1 && (!scratch || !tickets)) nsplit = 1;
+    if (nsplit > 1 && !scratch) nsplit = 1;
     if (part_floats(nsplit) * 4 >= (1ull << 31)) nsplit = 1;  // 31-bit descriptor offsets over the partials
     while (nsplit > 1 && part_floats(nsplit) > scratch_floats) --nsplit;
     int tpr = (tiles + 4 * nsplit - 1) / (4 * nsplit);
@@ -684,9 +743,14 @@ hipError_t launch_attention(const float* qkv, const long long* lens, int B, int 
       float* opart = nsplit > 1 ? scratch : nullptr;
       float* mlpart = nsplit > 1 ? scratch + (size_t)nsplit * M * d : nullptr;
       dim3 grid(tiles * nsplit, H, B), block(256);
+      if (ev0) (void)hipEventRecord(ev0, st);  // (small-grid path: plain marker events, this launch is not a roofline case)
       if (dk == 128) hipLaunchKernelGGL((k_attention_strip<128>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, tickets);
       else if (dk == 64) hipLaunchKernelGGL((k_attention_strip<64>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, tickets);
       else hipLaunchKernelGGL((k_attention_strip<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, tickets);
+      // without a ticket block (ns_config.row_epilogue = two_launch, or the phase's block is spent) the strips' partials are
+      // merged by a launch of their own: same layout, same split order, same arithmetic as the last arriver's merge
+      if (nsplit > 1 && !tickets) hipLaunchKernelGGL(k_attention_merge, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, opart, mlpart, (int)M, d, H, dk, nsplit, out);
+      if (ev1) (void)hipEventRecord(ev1, st);
       return hipGetLastError();
     }
   }
@@ -702,15 +766,24 @@ hipError_t launch_attention(const float* qkv, const long long* lens, int B, int 
     if (nsplit < 1) nsplit = 1;
     const int tps = (tiles + nsplit - 1) / nsplit;
     nsplit = (tiles + tps - 1) / tps;  // no empty ranges: 25 tiles over 16 ranges are 13 ranges of two
+  } else if (scratch && launch_planner_enabled()) {
+    // a launch that fills its last round of 256 workgroups badly (plan_key_split above)
+    nsplit = plan_key_split(blocks, tiles, dk, M, d);
+    while (nsplit > 1 && part_floats(nsplit) > scratch_floats) --nsplit;
+    const int tps = (tiles + nsplit - 1) / nsplit;
+    nsplit = (tiles + tps - 1) / tps;
   }
   float* opart = nsplit > 1 ? scratch : nullptr;
   float* mlpart = nsplit > 1 ? scratch + (size_t)nsplit * M * d : nullptr;
-  dim3 grid(qtiles * nsplit, H, B), block(256);
-  if (dk == 128) hipLaunchKernelGGL((k_attention<128>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr, nullptr, nullptr, 0, 0, 0);
-  else if (dk == 64) hipLaunchKernelGGL((k_attention<64>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr, nullptr, nullptr, 0, 0, 0);
-  else hipLaunchKernelGGL((k_attention<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, nullptr, nullptr, nullptr, nullptr, 0, 0, 0);
-  if (nsplit > 1)
-    hipLaunchKernelGGL(k_attention_merge, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, opart, mlpart, (int)M, d, H, dk, nsplit, out);
+  dim3 grid(qtiles * nsplit, H, B);
+  hipEvent_t k1 = nsplit > 1 ? nullptr : ev1;
+  if (dk == 128) launch_k_attention<128>(grid, st, ev0, k1, qkv, lens, S, d, c, out, nsplit, opart, mlpart, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, 0, 0, 0);
+  else if (dk == 64) launch_k_attention<64>(grid, st, ev0, k1, qkv, lens, S, d, c, out, nsplit, opart, mlpart, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, 0, 0, 0);
+  else launch_k_attention<32>(grid, st, ev0, k1, qkv, lens, S, d, c, out, nsplit, opart, mlpart, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, 0, 0, 0);
+  if (nsplit > 1) {
+    if (ev1) hipExtLaunchKernelGGL(k_attention_merge, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, nullptr, ev1, 0, opart, mlpart, (int)M, d, H, dk, nsplit, out);
+    else hipLaunchKernelGGL(k_attention_merge, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, opart, mlpart, (int)M, d, H, dk, nsplit, out);
+  }
   return hipGetLastError();
 }
 

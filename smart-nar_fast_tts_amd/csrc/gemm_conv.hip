@@ -30,6 +30,8 @@
 //
 // Operand reads use the freedom to permute k identically on both operands: lane-half h of MFMA step e in
 // group g consumes k = 8g + 4h + e, so each lane reads its 4 steps' operands with ONE ds_read_b128.
+#include <hip/hip_ext.h>
+#include <cstdlib>
 #include "rowln.h"
 
 namespace ns {
@@ -45,9 +47,15 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // (act(contraction + bias) + resid) write-through into p.Y, then draws a ticket on its row block's counter; the workgroup
 // that draws the last one (all ntn column tiles of the BM rows are then in memory) runs the row functions of rowln.h on
 // those rows — the same code, on the same values, as the separate k_layernorm / k_ln_linear_embed launch would: bit-identical.
-// Visibility across the 8 XCDs' private L2s / the CUs' L1s: sc1 (write-through) tile stores, every storing wave drains
-// vmcnt, barrier, ONE relaxed agent-scope fetch_add; the last arriver does ONE agent-scope acquire, then plain loads
-// (cdna_hip_programming.md Guideline 16, counter form).  The counters are zeroed by the first kernel of the forward phase.
+// Visibility across the 8 XCDs' private L2s / the CUs' L1s (cdna_hip_programming.md Guideline 16, counter form, with the
+// fences traded for cache-bypassing accesses): the tile goes out as sc1 (write-through) stores, every storing wave drains
+// vmcnt — the stores have then reached memory-side coherence — then a workgroup barrier and ONE relaxed agent-scope
+// fetch_add; the last arriver reads the rows back with sc1 LOADS, which cannot hit a stale line of this CU's L1 or this
+// XCD's L2, so it needs no acquire fence / cache invalidate (an agent-scope acquire here cost 900-1800 cycles per row
+// block).  The ordering rests on: (1) vmcnt(0) = the write-through stores are complete at the device-coherent level,
+// (2) the barrier orders every wave's drain before the ticket, (3) the RMW is performed at L2/memory in ticket order.
+// It is exercised under load by tests/test_gpu_stress.py (thousands of ticketed launches on four streams against the
+// two-launch form, bit for bit).  The counters are zeroed by the first kernel of the forward phase.
 template <int BM, int BN, int BK, int KS, int WGM = 2, int WGN = 2, bool ROWEPI = false, int TICKET = 0>  // TICKET: row width / 256, 0 = off
 __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, int ntn) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type does not exist in the host pass; it only needs the stub
@@ -403,9 +411,12 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
 }
 
 template <int BM, int BN, int BK, int KS = 1, int WGM = 2, int WGN = 2, bool ROWEPI = false, int TICKET = 0>
-static hipError_t launch_t(const ConvGemm& p, hipStream_t st) {
+static hipError_t launch_t(const ConvGemm& p, hipStream_t st, const LaunchTiming* tm = nullptr) {
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN, ROWEPI, TICKET>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, p, ntn);
+  if (tm && (tm->start || tm->stop))  // the events ride on this kernel's own dispatch packet (kernels.h LaunchTiming)
+    hipExtLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN, ROWEPI, TICKET>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, tm->start, tm->stop, 0, p, ntn);
+  else
+    hipLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN, ROWEPI, TICKET>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, p, ntn);
   return hipGetLastError();
 }
 
@@ -415,6 +426,11 @@ bool conv_gemm_ticket_ok(int M, int N, int Cin) {
 
 bool conv_gemm_row_epilogue_ok(int M, int N, int Cin) {
   return M > 0 && (N == 256 || N == 512) && Cin % 32 == 0;
+}
+
+bool launch_planner_enabled() {
+  static const bool on = [] { const char* e = getenv("NS_PLAN"); return !(e && e[0] == '0'); }();
+  return on;
 }
 
 // rows [begin, begin + count) of p as a launch of its own (plain epilogue: the row-indexed operands are X, Y, resid)
@@ -428,10 +444,87 @@ static ConvGemm row_range(const ConvGemm& p, int begin, int count) {
   return q;
 }
 
-static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bool allow_split);
-hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st) { return launch_conv_gemm_impl(p, st, true); }
+// ---------------------------------------------------------------------------------------------------------------------
+// Step-aware launch plan.  A launch's time is a staircase in its workgroup count — one step per 256 workgroups, one per CU,
+// whatever the tile (tools/lab/gemm_lab_plan.hip: flat inside a step, a full step more at 256 k + 1) — so ONE tile shape per
+// launch makes the forward's time a staircase in the batch size: every launch class crosses a multiple of 256 tiles at the
+// same row counts (round 3: B = 8 -> 9 cost +1.0 ms).  The planner prices every candidate with the measured model
+//     t(tile, M) = a(tile, chunks) + b(tile, chunks) * ceil(workgroups / 256)      chunks = KW * Cin / 32
+// and takes the cheapest of: one launch of any tile; FULL steps of a tall tile followed by the remaining rows on a finer one
+// (rows are independent; a convolution's taps reach across the cut through the operand pointers, ConvGemm::m_base keeps the
+// utterance positions).  Every candidate tile sums a row's contraction in the same order — no in-workgroup K split — so the
+// rows behind a cut carry the same bits as the rows ahead of it, and replicas of one utterance inside a batch stay
+// bit-identical wherever the cut falls.  (`hipExtAnyOrderLaunch` on the remainder — no barrier bit, so that it could start
+// while the main launch drains — was measured and does nothing on gfx950; the two launches are plain stream neighbours.)
+// a, b in us, fitted on one MI355X over chunks = 8 ... 80 (QKV, predictor k=3, FFN w_2, FFN w_1 k=9, PostNet k=5):
+struct TileModel { int bm, bn; float a0, a1, b0, b1; };
+enum TileId { T256, T128, T64W, T64, T64N, T32, N_TILES };
+static constexpr TileModel kTile[N_TILES] = {
+    {256, 256, 11.0f, 0.00f, 10.0f, 7.25f},  // 16 waves 8x2, one workgroup per CU: 0.91 of peak in full steps
+    {128, 256, 5.0f, 0.20f, 8.0f, 3.60f},    // 16 waves 4x4
+    {64, 256, 6.0f, 0.17f, 3.6f, 1.83f},     // 8 waves 2x4, two workgroups per CU
+    {64, 128, 5.5f, 0.09f, 1.6f, 0.93f},     // 8 waves 2x4
+    {64, 64, 5.0f, 0.20f, 1.2f, 0.46f},      // 4 waves 2x2
+    {32, 128, 5.0f, 0.23f, 1.0f, 0.45f},     // 4 waves 1x4
+};
+static long tile_wgs(int t, long M, int N) { return ((M + kTile[t].bm - 1) / kTile[t].bm) * ((N + kTile[t].bn - 1) / kTile[t].bn); }
+static float tile_time(int t, long M, int N, int chunks) {
+  const long steps = (tile_wgs(t, M, N) + 255) / 256;
+  // between near-ties the taller tile (fewer passes over the weights, settled by forward A/B runs in round 3) keeps the launch
+  return (kTile[t].a0 + kTile[t].a1 * chunks + (kTile[t].b0 + kTile[t].b1 * chunks) * (float)steps) * (1.0f + 0.01f * (float)t);
+}
+static hipError_t launch_tile(int t, const ConvGemm& p, hipStream_t st, const LaunchTiming* tm) {
+  switch (t) {
+    case T256: return launch_t<256, 256, 32, 1, 8, 2>(p, st, tm);
+    case T128: return launch_t<128, 256, 32, 1, 4, 4>(p, st, tm);
+    case T64W: return launch_t<64, 256, 32, 1, 2, 4>(p, st, tm);
+    case T64: return launch_t<64, 128, 32, 1, 2, 4>(p, st, tm);
+    case T64N: return launch_t<64, 64, 32, 1, 2, 2>(p, st, tm);
+    default: return launch_t<32, 128, 32, 1, 1, 4>(p, st, tm);
+  }
+}
+struct RowPlan { int main_tile, main_rows, rem_tile; float us; };  // main_rows == 0: one launch of rem_tile
+static RowPlan plan_rows(long M, int N, int chunks) {
+  constexpr float CUT_US = 3.0f;  // a second launch: its ramp is in a(tile), this is the boundary itself
+  RowPlan best{-1, 0, T64, 1e30f};
+  for (int t = 0; t < N_TILES; ++t) {
+    if (kTile[t].bn > N && t != T32 && t != T64N && t != T64) continue;  // (a 256-wide tile on a narrower output: never)
+    const float c = tile_time(t, M, N, chunks);
+    if (c < best.us) best = RowPlan{-1, 0, t, c};
+  }
+  for (int t = T256; t <= T64; ++t) {
+    if (kTile[t].bn > N) continue;
+    const long ntn = (N + kTile[t].bn - 1) / kTile[t].bn;
+    const long per = (256 / ntn) * kTile[t].bm;  // rows of one full step
+    if (per <= 0) continue;
+    for (long k = M / per; k >= 1 && k >= M / per - 1; --k) {
+      const long rows = k * per, rest = M - rows;
+      if (rest <= 0) continue;
+      const float cm = tile_time(t, rows, N, chunks);
+      for (int r = t + 1; r < N_TILES; ++r) {
+        if (kTile[r].bn > N && r < T64) continue;
+        const float c = cm + CUT_US + tile_time(r, rest, N, chunks);
+        if (c < best.us) best = RowPlan{t, (int)rows, r, c};
+      }
+    }
+  }
+  return best;
+}
 
-static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bool allow_split) {
+// full-row tile (32 rows x N, one step per 256 tiles) against 64x64 tiles with the ticketed last-arriver epilogue (+ ~3 us)
+int conv_gemm_ln_form(int M, int N, int Cin, int KW) {
+  if (!launch_planner_enabled() || !conv_gemm_ticket_ok(M, N, Cin)) return LN_FULL_ROW;
+  const int chunks = KW * (Cin / 32), nv = N / 256;
+  const long full_steps = (((long)M + 31) / 32 + 255) / 256;
+  const float full = 5.0f + 0.1f * chunks + (1.9f + 0.95f * chunks) * (float)nv * (float)full_steps;
+  const float tick = tile_time(T64N, M, N, chunks) / (1.0f + 0.01f * T64N) + 3.0f;
+  return tick < 0.95f * full ? LN_TICKET : LN_FULL_ROW;
+}
+
+static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bool allow_split, const LaunchTiming* tm);
+hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st, const LaunchTiming* tm) { return launch_conv_gemm_impl(p, st, true, tm); }
+
+static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bool allow_split, const LaunchTiming* tm) {
   ConvGemm p = p_in;
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if (p.m_base != 0 && p.epi != EPI_NONE) return hipErrorInvalidValue;
@@ -448,10 +541,10 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
     auto wgs = [&](long rows, int bn) { return rows * ((p.N + bn - 1) / bn); };
     const int nch = p.KW * (p.Cin / 32);
 #define NS_TICKET_LADDER(NVT)                                                                                                        \
-    if (wgs(rows32, 32) <= 256) return nch >= 16 ? launch_t<32, 32, 32, 8, 1, 1, false, NVT>(p, st) : launch_t<32, 32, 32, 4, 1, 1, false, NVT>(p, st); \
-    if (wgs(rows32, 64) <= 256) return launch_t<32, 64, 32, 4, 1, 2, false, NVT>(p, st);                                             \
-    if (wgs(rows32, 128) <= 512) return launch_t<32, 128, 32, 2, 1, 4, false, NVT>(p, st);                                           \
-    return launch_t<64, 64, 32, 1, 2, 2, false, NVT>(p, st);
+    if (wgs(rows32, 32) <= 256) return nch >= 16 ? launch_t<32, 32, 32, 8, 1, 1, false, NVT>(p, st, tm) : launch_t<32, 32, 32, 4, 1, 1, false, NVT>(p, st, tm); \
+    if (wgs(rows32, 64) <= 256) return launch_t<32, 64, 32, 4, 1, 2, false, NVT>(p, st, tm);                                             \
+    if (wgs(rows32, 128) <= 512) return launch_t<32, 128, 32, 2, 1, 4, false, NVT>(p, st, tm);                                           \
+    return launch_t<64, 64, 32, 1, 2, 2, false, NVT>(p, st, tm);
     if (p.N == 256) { NS_TICKET_LADDER(1) }
     NS_TICKET_LADDER(2)
 #undef NS_TICKET_LADDER
@@ -459,8 +552,8 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
   if (p.epi != EPI_NONE) {
     // full-row tile: 32 rows x N columns, N / 32 waves side by side with one 32x32 MFMA tile each
     if (!conv_gemm_row_epilogue_ok(p.M, p.N, p.Cin) || (p.epi == EPI_LN && p.ldy != p.N) || (p.resid && (p.ldr & 3))) return hipErrorInvalidValue;
-    if (p.N == 256) return launch_t<32, 256, 32, 1, 1, 8, true>(p, st);
-    return launch_t<32, 512, 32, 1, 1, 16, true>(p, st);
+    if (p.N == 256) return launch_t<32, 256, 32, 1, 1, 8, true>(p, st, tm);
+    return launch_t<32, 512, 32, 1, 1, 16, true>(p, st, tm);
   }
   const bool bk32 = (p.Cin % 32) == 0;
   // Tile / wave-grid choice (tools/lab sweeps on the path's shapes, MI355X, same-run comparisons).  What wins is
@@ -473,8 +566,25 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
   // Narrow outputs (N = 80: mel_linear, the PostNet's last layer): three 32-column tiles instead of a 128-wide tile that
   // is 37 % padding (tools/lab/gemm_lab_n80.hip: k5 512->80, M=16160 99.8 -> 85.2 us; M=64640 360 -> 310 us)
   if (bk32 && p.N > 64 && p.N <= 96 && p.KW * p.Cin >= 1024) {
-    if (rows64 >= 512) return launch_t<64, 96, 32, 1, 2, 3>(p, st);
-    if (rows32 >= 400) return launch_t<32, 96, 32, 4, 1, 3>(p, st);
+    if (launch_planner_enabled()) {
+      // at every row count beyond the small-grid ladder's 32x64 rung: 32 rows x 96 columns with four K groups, one workgroup
+      // per CU (tools/lab/gemm_lab_n80b.hip, k5 512->80, us: M = 5050 46.9 (32x128 KS2) -> 36.8, 9090 87.1 -> 72.4,
+      // 12120 84.9 -> 71.1, 32480 158.5 (64x96) -> 140.9; below M ~ 4100 the ladder wins, 29.1 vs 37.2)
+      if (wgs(rows32, 64) > 256) return launch_t<32, 96, 32, 4, 1, 3>(p, st, tm);
+    } else {
+      if (rows64 >= 512) return launch_t<64, 96, 32, 1, 2, 3>(p, st, tm);
+      if (rows32 >= 400) return launch_t<32, 96, 32, 4, 1, 3>(p, st, tm);
+    }
+  }
+  // Everything from about one step of the 64x128 tile upwards: the step-aware plan (above).  Below that the launch is one
+  // partial step whatever the tile, and the small-grid ladder at the end of this function (in-workgroup K split) is faster.
+  if (launch_planner_enabled() && allow_split && bk32 && p.N >= 128 && wgs(rows64, 128) > 256) {
+    const RowPlan pl = plan_rows(p.M, p.N, p.KW * (p.Cin / 32));
+    if (pl.main_rows == 0) return launch_tile(pl.rem_tile, p, st, tm);
+    const LaunchTiming t0{tm ? tm->start : nullptr, nullptr}, t1{nullptr, tm ? tm->stop : nullptr};
+    const hipError_t e = launch_tile(pl.main_tile, row_range(p, 0, pl.main_rows), st, &t0);
+    if (e != hipSuccess) return e;
+    return launch_tile(pl.rem_tile, row_range(p, pl.main_rows, p.M - pl.main_rows), st, &t1);
   }
   // Mid-size row counts on the long-K convolutions (FFN k=9, PostNet k=5): a few utterances, or a packed variable-length
   // batch.  Between the small-grid ladder's 512 workgroups and the point where whole rounds of the 64-row tiles average out,
@@ -485,7 +595,7 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
   // as much as the loop and three 64x128 workgroups per CU interleave them better than two 64x256 ones.  Measured in the
   // FORWARD (alternating same-box runs; the lab loop had it the other way round at config 5): config 2 5.476 -> 5.456 ms,
   // config 4 57.50 -> 57.33 ms, config 5 unchanged.
-  if (bk32 && p.N >= 512 && p.KW * p.Cin <= 512 && wgs(rows64, 128) > 256) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
+  if (bk32 && p.N >= 512 && p.KW * p.Cin <= 512 && wgs(rows64, 128) > 256) return launch_t<64, 128, 32, 1, 2, 4>(p, st, tm);
   // ... unless a taller 16-wave tile, one workgroup per CU, fills its rounds: fewer passes over the weights, and with one
   // or two rounds there is nothing a second co-resident workgroup could hide.  Settled by alternating whole-forward runs on
   // one box (tools/ab_forward.sh), per launch: 256x256 — decoder k=9 GEMM 547.7 -> 539.7 us at config 2 (254 tiles, one round),
@@ -495,8 +605,8 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
   if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400) {
     auto fill = [](long n) { return (double)n / (double)(((n + 255) / 256) * 256); };  // of the last round, one workgroup per CU
     const long c256 = wgs((p.M + 255) / 256, 256), c128 = wgs((p.M + 127) / 128, 256);
-    if (c256 >= 200 && c256 <= 512 && fill(c256) >= 0.95) return launch_t<256, 256, 32, 1, 8, 2>(p, st);  // measured for one and two rounds only
-    if (c128 <= 512 && fill(c128) >= 0.95) return launch_t<128, 256, 32, 1, 4, 4>(p, st);
+    if (c256 >= 200 && c256 <= 512 && fill(c256) >= 0.95) return launch_t<256, 256, 32, 1, 8, 2>(p, st, tm);  // measured for one and two rounds only
+    if (c128 <= 512 && fill(c128) >= 0.95) return launch_t<128, 256, 32, 1, 4, 4>(p, st, tm);
     // A row count somewhat above one or two FULL rounds of the 256x256 tile (packed variable-length batches: M is whatever
     // the utterances add up to; a uniform batch of one utterance more than a round holds) and too small for the many-round
     // 64x256 form to average its partial last round away: the full rounds go to the tall tile at its single-round rate, the
@@ -509,9 +619,10 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
     if (allow_split && p.epi == EPI_NONE && per >= 1 && p.M > 256 * per && wgs(rows64, 256) < 4 * 512) {
       const long r256 = 256 * per;
       const long n = p.M / r256 > 2 ? 2 : p.M / r256;
-      const hipError_t e = launch_t<256, 256, 32, 1, 8, 2>(row_range(p, 0, (int)(n * r256)), st);
+      const LaunchTiming t0{tm ? tm->start : nullptr, nullptr}, t1{nullptr, tm ? tm->stop : nullptr};
+      const hipError_t e = launch_t<256, 256, 32, 1, 8, 2>(row_range(p, 0, (int)(n * r256)), st, &t0);
       if (e != hipSuccess) return e;
-      return launch_conv_gemm_impl(row_range(p, (int)(n * r256), (int)(p.M - n * r256)), st, false);
+      return launch_conv_gemm_impl(row_range(p, (int)(n * r256), (int)(p.M - n * r256)), st, false, &t1);
     }
   }
   if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400) {
@@ -520,14 +631,14 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
     // so when the half-size tile needs fewer than 2 x 0.93 as many steps it wins by up to a step of the big one
     // (M = 10 240: 368 vs 413 us).  Beyond eight steps the partial last step no longer matters and the wider tile's rate does.
     const long sc = (wgs(rows64, 256) + 255) / 256, sd = (wgs(rows64, 128) + 255) / 256;
-    if (sc <= 8 && p.N % 128 == 0 && (double)sd * 0.5 < 0.93 * (double)sc) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
-    return launch_t<64, 256, 32, 1, 2, 4>(p, st);
+    if (sc <= 8 && p.N % 128 == 0 && (double)sd * 0.5 < 0.93 * (double)sc) return launch_t<64, 128, 32, 1, 2, 4>(p, st, tm);
+    return launch_t<64, 256, 32, 1, 2, 4>(p, st, tm);
   }
-  if (bk32 && p.N >= 128 && wgs(rows64, 128) > 256) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
+  if (bk32 && p.N >= 128 && wgs(rows64, 128) > 256) return launch_t<64, 128, 32, 1, 2, 4>(p, st, tm);
   // The remainder of a split plan stays on tiles WITHOUT an in-workgroup K split: every such tile sums a row's contraction in
   // the same order, so the rows behind the cut carry the same bits as the rows ahead of it (replicas of one utterance inside
   // a batch stay bit-identical wherever the cut falls); the K-split ladder below rounds differently.
-  if (!allow_split && bk32 && p.N >= 128) return launch_t<64, 128, 32, 1, 2, 4>(p, st);
+  if (!allow_split && bk32 && p.N >= 128) return launch_t<64, 128, 32, 1, 2, 4>(p, st, tm);
   // Fewer output tiles than that (encoder-side GEMMs, single-utterance latency): a workgroup's time is set by how fast
   // ONE CU can pull its operand panels, (BM + BN) * K * 4 bytes, through LDS-DMA, so what matters is to put every CU to
   // work — the smallest tile that still yields <= 256 workgroups (one round, one per CU) — and to spend the rest of the
@@ -537,16 +648,16 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
   //        M=788 k5 512->512: 51.2 -> 31.8 (32x64 KS4);  M=788 k9 256->1024: 49.5 -> 45.4 (32x128 KS2).
   if (bk32) {
     const int nch = p.KW * (p.Cin / 32);
-    if (wgs(rows32, 32) <= 256) return nch >= 16 ? launch_t<32, 32, 32, 8, 1, 1>(p, st) : launch_t<32, 32, 32, 4, 1, 1>(p, st);
-    if (wgs(rows32, 64) <= 256) return launch_t<32, 64, 32, 4, 1, 2>(p, st);
-    if (wgs(rows32, 128) <= 512) return launch_t<32, 128, 32, 2, 1, 4>(p, st);
-    return launch_t<64, 64, 32>(p, st);
+    if (wgs(rows32, 32) <= 256) return nch >= 16 ? launch_t<32, 32, 32, 8, 1, 1>(p, st, tm) : launch_t<32, 32, 32, 4, 1, 1>(p, st, tm);
+    if (wgs(rows32, 64) <= 256) return launch_t<32, 64, 32, 4, 1, 2>(p, st, tm);
+    if (wgs(rows32, 128) <= 512) return launch_t<32, 128, 32, 2, 1, 4>(p, st, tm);
+    return launch_t<64, 64, 32>(p, st, tm);
   }
-  if (wgs(rows32, 32) <= 512) return launch_t<32, 32, 16, 4, 1, 1>(p, st);
+  if (wgs(rows32, 32) <= 512) return launch_t<32, 32, 16, 4, 1, 1>(p, st, tm);
   // Cin = 80 (the PostNet's first layer): wider tiles once there are enough of them (M=16160 77 -> 73.5 us, M=64640 269 -> 250 us)
-  if (p.N >= 256 && wgs(rows64, 256) >= 1024) return launch_t<64, 256, 16, 1, 2, 4>(p, st);
-  if (p.N >= 128 && wgs(rows64, 128) >= 512) return launch_t<64, 128, 16, 1, 2, 4>(p, st);
-  return launch_t<64, 64, 16>(p, st);
+  if (p.N >= 256 && wgs(rows64, 256) >= 1024) return launch_t<64, 256, 16, 1, 2, 4>(p, st, tm);
+  if (p.N >= 128 && wgs(rows64, 128) >= 512) return launch_t<64, 128, 16, 1, 2, 4>(p, st, tm);
+  return launch_t<64, 64, 16>(p, st, tm);
 }
 
 }  // namespace ns

@@ -65,7 +65,18 @@ struct ConvGemm {
   RowEpilogue e;
   RowMap rm;                    // packed rows: tap windows come from row_t / row_w instead of m % S / S
 };
-hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st);
+// Optional timing of one launch_conv_gemm / launch_attention call: the events ride ON the dispatch packets
+// (hipExtLaunchKernel's start / stop events: the kernel's own begin / end timestamps), so timing a launch adds no marker
+// packet and no idle gap to the stream — hipEventRecord pairs around the heavy launches cost ~6 us each, 3 % of a forward.
+// A plan of several launches gets `start` on its first and `stop` on its last kernel.  nullptr / {nullptr, nullptr} = untimed.
+struct LaunchTiming { hipEvent_t start, stop; };
+hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st, const LaunchTiming* tm = nullptr);
+// How a GEMM with a row epilogue (LayerNorm / predictor tail over whole N-wide rows) is best launched for M rows — the step-aware
+// planner's answer (gemm_conv.hip): the 32-row full-row tile, or narrower tiles with the ticketed last-arriver epilogue.
+enum LnForm : int { LN_FULL_ROW = 0, LN_TICKET = 1 };
+int conv_gemm_ln_form(int M, int N, int Cin, int KW);
+// NS_PLAN=0 in the environment: the round-3 one-tile-per-launch rules (A/B runs of the planner; read once)
+bool launch_planner_enabled();
 // opt-in "bf16x3" precision mode (gemm_bf16x3.hip): same contraction from an exact 3-way bf16 split of both operands
 bool conv_gemm_b3_ok(int M, int N, int Cin, int KW, int epi);  // epi: EPI_NONE or EPI_LN
 hipError_t launch_conv_gemm_b3(const ConvGemm& p, hipStream_t st);
@@ -86,7 +97,12 @@ constexpr int ATT_SPLIT_MAX = 16, ATT_SPLIT_MAX_BLOCKS = 128;
 inline int attention_ticket_ints(int B, int S, int H) { return B * H * ((S + 31) / 32); }
 // rm (packed rows): utterance b's rows start at rm->off[b] and number rm->win[b] <= S (S = the longest window); no split-key path
 hipError_t launch_attention(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, float* scratch,
-                            size_t scratch_floats, int* tickets, hipStream_t st, const RowMap* rm = nullptr);
+                            size_t scratch_floats, int* tickets, hipStream_t st, const RowMap* rm = nullptr, const LaunchTiming* tm = nullptr);
+// key ranges per 128-query tile the dense launch of (B, S, H, dk) will use when it has the scratch for them (1 = no split):
+// the caller sizes `scratch` as attention_split(...) * B*S*(H*dk + 2*H) floats
+int attention_split(int B, int S, int H, int dk);
+// the same for a packed launch: att_wgs workgroups on the work list, S = the longest window, Mp packed rows
+int attention_split_packed(int att_wgs, int S, int dk, size_t Mp, int d);
 
 // ---- row kernels (rowops.hip) -----------------------------------------------------------------
 // y = LayerNorm_C(x) * g + b ; rows with t >= lens[b] are written as zero when lens != nullptr

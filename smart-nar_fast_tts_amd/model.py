@@ -49,6 +49,9 @@ def config_struct(preprocess_config: dict, model_config: dict) -> _lib.NsConfig:
         # EXTENSION key: "bf16x3" opts the large decoder-FFN / PostNet contractions into the split-bf16 matrix-core path
         # (include/nar_fs2.h ns_config.matmul_bf16x3); "fp32" (default) is the reference's arithmetic everywhere
         matmul_bf16x3={"fp32": 0, "bf16x3": 1}[model_config.get("matmul", "fp32")],
+        # EXTENSION key (tests): "two_launch" never draws a ticket — LayerNorm / predictor tails / attention merges of small
+        # grids run as separate launches instead of last-arriver epilogues (include/nar_fs2.h ns_config.row_epilogue); same bits
+        row_epilogue={"fused": 0, "two_launch": 1}[model_config.get("row_epilogue", "fused")],
     )
 
 
@@ -88,8 +91,39 @@ def _block_layout(specs):
     return at, max(off, _OutputBlock._ALIGN)
 
 
+class ForwardOutput(tuple):
+    """The reference's 12-tuple (model/fastspeech2_align.py:87-100) plus, as attributes, what belongs to THIS call only:
+    ``status`` — the [B] int32 device tensor of per-utterance NS_STATUS_* words (include/nar_fs2.h) — and ``check()``,
+    which raises what a synchronous forward raises on the spot (for forwards issued with ``async_status=True``).  Indexing,
+    unpacking and ``len()`` are the plain tuple's, so positional consumers (utils/tools.py:158-171) see no difference."""
+
+    def __new__(cls, items, status=None, n_vocab=0):
+        self = super().__new__(cls, items)
+        self.status = status
+        self._n_vocab = n_vocab
+        return self
+
+    def check(self):
+        """Synchronises with the forward that produced this output; IndexError for a token id outside the vocabulary
+        (nn.Embedding, transformer/Models.py:89), ValueError when an utterance was cut off at ``max_mel_len``.
+        Returns the status words as a list."""
+        if self.status is None:
+            return []
+        words = self.status.cpu().tolist()
+        bad = [i for i, w in enumerate(words) if w & _lib.STATUS_BAD_TOKEN]
+        if bad:
+            raise IndexError(f"index out of range in self: token id outside [0, {self._n_vocab}) in utterance(s) {bad}")
+        cut = [i for i, w in enumerate(words) if w & _lib.STATUS_TRUNCATED]
+        if cut:
+            raise ValueError(f"max_mel_len is smaller than the longest utterance: utterance(s) {cut} were cut off")
+        return words
+
+
 class FastSpeech2Align:
-    """FastSpeech2 (inference) — HIP/gfx950 implementation of the reference module of the same name."""
+    """FastSpeech2 (inference) — HIP/gfx950 implementation of the reference module of the same name.
+
+    Threading: one instance serves ONE host thread at a time (like the reference module under its single-threaded caller,
+    synthesize.py:59-76); several HIP streams from that thread are fine.  Use one instance per thread / process otherwise."""
 
     def __init__(self, preprocess_config: dict, model_config: dict):
         self.model_config = model_config
@@ -278,7 +312,16 @@ class FastSpeech2Align:
 
     # ---- measurement hook (bench.py roofline leg) ----------------------------------------------------
     def profile_dominant_kernel(self, on: bool = True):
-        _lib.check(self._lib.ns_profile_enable(self._h, int(on)), "ns_profile_enable")
+        """Time slot 0 only (the dominant kernel): a timed launch costs its stream ~5 us, so the headline region carries
+        four of them per forward, not eleven."""
+        self.profile_slots((0,) if on else ())
+
+    def profile_slots(self, slots=(0, 1, 2)):
+        """Time exactly these launch groups (include/nar_fs2.h NS_PROFILE_SLOT); () switches the hook off."""
+        mask = 0
+        for i in slots:
+            mask |= 2 << int(i)
+        _lib.check(self._lib.ns_profile_enable(self._h, mask), "ns_profile_enable")
 
     PROFILE_SLOTS = ("ffn_w1", "attention", "postnet_mid")  # include/nar_fs2.h: slots of ns_profile_read_slot
 
@@ -356,37 +399,34 @@ class FastSpeech2Align:
         else:
             done.synchronize()
 
-    def check_status(self):
-        """Raise what the synchronous path raises on the spot, for the most recent forward issued in capacity mode
-        (``max_mel_len=<int>``): IndexError for a token id outside the vocabulary (nn.Embedding, transformer/Models.py:89),
-        ValueError when an utterance turned out longer than ``max_mel_len`` (its frames past it were cut off).
-        Synchronises with that forward; returns the [B] status words (include/nar_fs2.h NS_STATUS_*) as a list."""
-        st = getattr(self, "last_status", None)
-        if st is None:
-            return []
-        words = st.cpu().tolist()
-        bad = [i for i, w in enumerate(words) if w & _lib.STATUS_BAD_TOKEN]
-        if bad:
-            raise IndexError(f"index out of range in self: token id outside [0, {self._cfg.n_vocab}) in utterance(s) {bad}")
-        cut = [i for i, w in enumerate(words) if w & _lib.STATUS_TRUNCATED]
-        if cut:
-            raise ValueError(f"max_mel_len is smaller than the longest utterance: utterance(s) {cut} were cut off")
-        return words
+    def check_status(self, out=None):
+        """``out.check()`` for the given forward output; without an argument, for the most recent forward of this model
+        (a convenience for single-stream callers: the per-call ``ForwardOutput.status`` is what concurrent callers use)."""
+        out = out if out is not None else getattr(self, "_last_out", None)
+        return [] if out is None else out.check()
+
+    @property
+    def last_status(self):
+        out = getattr(self, "_last_out", None)
+        return None if out is None else out.status
 
     def forward(self, speakers, texts, src_lens, max_src_len, mels=None, mel_lens=None, max_mel_len=None,
-                p_targets=None, e_targets=None, p_control=1.0, e_control=1.0):
+                p_targets=None, e_targets=None, p_control=1.0, e_control=1.0, *, async_status=False):
         """model/fastspeech2_align.py:30-100, inference branch.  ``speakers`` is accepted and ignored
-        (no speaker embedding exists in the reference; multi_speaker is False).
+        (no speaker embedding exists in the reference; multi_speaker is False).  Returns the reference's 12-tuple
+        (a ``ForwardOutput``: the tuple plus this call's ``status`` tensor).
 
         Extensions on ``max_mel_len`` (the reference itself cannot run with it set at inference: its mask is built from
         max(mel_len), model/modules.py:136-137; the `max_len` semantics followed are model/modules.py:128-131,204-213):
 
-        * an ``int``: CAPACITY MODE.  The mel axis is padded and masked to that length and the whole forward is enqueued
-          without a host synchronisation (nothing waits for ``mel_lens``).  An utterance longer than the capacity is cut off
-          and a bad token id cannot raise on the spot; both are recorded per utterance on the device and raised by
-          ``check_status()``.
+        * an ``int``: the mel axis is padded and masked to that length.  SYNCHRONOUS like the default path: ``ValueError`` when
+          it is smaller than the longest utterance, ``IndexError`` for a token id outside the vocabulary, both on the spot.
         * a callable ``f(local_max_tensor) -> int`` (e.g. ``sharding.global_max``, multi-GPU global-pad mode):
-          synchronous like the default path, padded to the returned length."""
+          synchronous as well, padded to the returned length.
+        * an ``int`` together with the keyword-only ``async_status=True``: CAPACITY MODE, an explicit opt-in.  The whole forward
+          is enqueued without a host synchronisation (nothing waits for ``mel_lens``).  An utterance longer than the capacity is
+          CUT OFF and a bad token id reads embedding row 0; nothing can raise on the spot.  Both are recorded per utterance in
+          the returned output's ``status`` tensor: call ``out.check()`` (or ``model.check_status(out)``) before trusting it."""
         if mel_lens is not None:
             raise NotImplementedError(
                 "teacher-forced / training branch is out of scope; in the reference it calls an undefined "
@@ -449,21 +489,24 @@ class FastSpeech2Align:
                 blk1.ptr("mel_lens"), blk1.ptr("p_pred"), blk1.ptr("e_pred"), _lib.ptr(pin), st), "ns_forward_durations")
             blk2 = ws_dec = None
             lens_on_host = False
-            if isinstance(max_mel_len, (int, np.integer)) and not isinstance(max_mel_len, bool):
+            fixed_T = isinstance(max_mel_len, (int, np.integer)) and not isinstance(max_mel_len, bool)
+            if async_status and not fixed_T:
+                raise ValueError("async_status=True needs max_mel_len=<int>: without a host read the mel axis must be fixed by the caller")
+            if fixed_T and int(max_mel_len) < 0:
+                raise ValueError(f"max_mel_len ({int(max_mel_len)}) is negative")
+            if fixed_T and async_status:
                 # CAPACITY MODE (model/modules.py:128-131,204-213 `max_len` semantics): the caller fixes the mel axis, so phase 2
                 # is enqueued right behind phase 1 — no event wait, no host read.  What the synchronous path checks on the host
                 # (token ids in range, T >= the longest utterance) lands in `status` on the device: check_status() raises later.
                 T = int(max_mel_len)
-                if T < 0:
-                    raise ValueError(f"max_mel_len ({T}) is negative")
             else:
                 # the one device->host read: output shapes depend on max(mel_len)
                 # (the reference syncs here too: utils/tools.py:92, plus B*L .item() calls at model/modules.py:222)
                 # (a token id outside [0, n_vocab) comes back as mel_len = -1 for its utterance; nn.Embedding raises IndexError)
                 # (the kernel that produces mel_lens also wrote them into pinned host memory: a stream sync, no D2H copy)
-                hint = self._t_hint.get((B, L))
+                hint = int(max_mel_len) if fixed_T else self._t_hint.get((B, L))
                 if hint is not None and p_targets is None and e_targets is None:
-                    Tc = hint + max(8, hint >> 3)
+                    Tc = hint if fixed_T else hint + max(8, hint >> 3)
                     blk2 = _OutputBlock(phase2_outputs(Tc), dev)
                     ws_dec = self._workspace("dec", self._ws_bytes("dec", B, L, Tc), sh)
                 self._wait_phase1(dev)
@@ -472,7 +515,12 @@ class FastSpeech2Align:
                 if int(pin_np.min()) < 0:
                     bad = [i for i, v in enumerate(pin_np.tolist()) if v < 0]
                     raise IndexError(f"index out of range in self: token id outside [0, {self._cfg.n_vocab}) in utterance(s) {bad}")
-                if callable(max_mel_len):
+                if fixed_T:
+                    if int(max_mel_len) < T:
+                        cut = [i for i, v in enumerate(pin_np.tolist()) if v > int(max_mel_len)]
+                        raise ValueError(f"max_mel_len ({int(max_mel_len)}) is smaller than the longest utterance ({T}): utterance(s) {cut}")
+                    T = int(max_mel_len)
+                elif callable(max_mel_len):
                     longest = T
                     T = int(max_mel_len(torch.tensor(longest, device=dev)))
                     if T < longest:
@@ -489,6 +537,11 @@ class FastSpeech2Align:
                 ws_dec = self._workspace("dec", self._ws_bytes("dec", B, L, max(T, 1)), sh)
             else:
                 blk2.layout(phase2_outputs(T))  # same block, offsets for the actual T (it fits: T <= capacity)
+                # the scratch was sized for the capacity guess Tc, and ns_decoder_ws_bytes is NOT monotonic in T (a shorter
+                # mel axis can take attention's split-key path, whose partials outweigh everything else): size it for T itself
+                need = self._ws_bytes("dec", B, L, max(T, 1))
+                if ws_dec.numel() < need:
+                    ws_dec = self._workspace("dec", need, sh)
             # forward() hands p_targets / e_targets to the variance adaptor in the inference branch too
             # (model/fastspeech2_align.py:70-78): the embedding then comes from bucketize(target)
             tg0 = target("p_targets", p_targets, (B, T)) if p_frame else None
@@ -505,8 +558,10 @@ class FastSpeech2Align:
             # the GPU is busy with phase 2 from here on: cut the caller's tensors out of the two blocks
             log_d, d_rounded, src_masks = blk1.view("log_d"), blk1.view("d_rounded"), blk1.view("src_masks")
             out_mel_lens, status = blk1.view("mel_lens"), blk1.view("status")
-            self.last_status = status
             mel, post, mel_masks = blk2.view("mel"), blk2.view("post"), blk2.view("mel_masks")
             p_pred = blk2.view("p_pred") if p_frame else blk1.view("p_pred")
             e_pred = blk2.view("e_pred") if e_frame else blk1.view("e_pred")
-        return (mel, post, p_pred, e_pred, log_d, d_rounded, src_masks, mel_masks, src_lens, out_mel_lens, None, None)
+        out = ForwardOutput((mel, post, p_pred, e_pred, log_d, d_rounded, src_masks, mel_masks, src_lens, out_mel_lens, None, None),
+                            status=status, n_vocab=self._cfg.n_vocab)
+        self._last_out = out
+        return out

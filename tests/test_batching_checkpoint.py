@@ -209,3 +209,38 @@ def test_adopted_arena_survives_a_device_rebind():
     del old
     torch.cuda.empty_cache()
     assert torch.equal(dst(*a, L)[1], ref[1])
+
+
+@pytest.mark.gpu
+def test_adopt_arena_refuses_bytes_that_are_not_this_models_arena():
+    """the arena travels between processes as bytes; bytes that were never finalized, that belong to another
+    configuration, or that another layout version packed must be refused by ns_adopt_arena instead of silently misread
+    (round 3 grew the layout by the PostNet constants: an old same-size arena would have left them garbage)."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    cfg = wl.model_config("tiny")
+    src = FastSpeech2Align(wl.preprocess_config(), cfg).to("cuda").eval()
+    src.load_state_dict(wl.synth_state_dict(cfg, frames_per_phoneme=4.0))
+    # never finalized: zeros
+    dst = FastSpeech2Align(wl.preprocess_config(), cfg).to("cuda").eval()
+    dst.arena_tensor().zero_()
+    with pytest.raises(RuntimeError, match="magic"):
+        dst.adopt_arena()
+    # right bytes, one header word off: the layout version
+    dst.arena_tensor().copy_(src.arena_tensor())
+    hdr = dst.arena_tensor()[:64].view(torch.int32)
+    ver = int(hdr[1])
+    hdr[1] = ver - 1
+    with pytest.raises(RuntimeError, match="layout version"):
+        dst.adopt_arena()
+    hdr[1] = ver
+    dst.adopt_arena()  # intact again: accepted
+    # another configuration whose arena happens to be handed over: refused by size or by the config hash
+    cfg2 = wl.model_config("tiny")
+    cfg2["variance_embedding"] = dict(cfg2["variance_embedding"], n_bins=cfg2["variance_embedding"]["n_bins"] * 2)
+    other = FastSpeech2Align(wl.preprocess_config(), cfg2).to("cuda").eval()
+    n = min(other.arena_tensor().numel(), src.arena_tensor().numel())
+    other.arena_tensor()[:n].copy_(src.arena_tensor()[:n])
+    with pytest.raises(RuntimeError, match="arena size|different ns_config"):
+        other.adopt_arena()

@@ -625,9 +625,10 @@ def test_max_mel_len_global_pad_mode():
 
 
 def test_capacity_mode_is_sync_free_and_bit_identical():
-    """max_mel_len=<int> (model/modules.py:128-131,204-213 `max_len` semantics): phase 2 is enqueued right behind phase 1,
-    nothing on the host waits for mel_lens.  With the capacity equal to the longest utterance every output is BIT-identical
-    to the synchronous path; what the synchronous path raises on the spot arrives through check_status()."""
+    """max_mel_len=<int> with the explicit opt-in async_status=True (model/modules.py:128-131,204-213 `max_len` semantics):
+    phase 2 is enqueued right behind phase 1, nothing on the host waits for mel_lens.  With the capacity equal to the longest
+    utterance every output is BIT-identical to the synchronous path; what the synchronous path raises on the spot arrives
+    through the returned output's own status (out.check()), per call."""
     from unittest import mock
 
     from smart_nar_fast_tts_amd import _lib
@@ -638,43 +639,86 @@ def test_capacity_mode_is_sync_free_and_bit_identical():
     m.packed_rows = False  # capacity mode runs on the padded grid (the host never learns the lengths): compare grid with grid
     base = run_gpu(m, z, meta)
     T = base[0].shape[1]
+    nb = len(z["in_src_lens"])
     args = (dev(z["speakers"]), dev(z["texts"]), dev(z["in_src_lens"]), int(meta["L"]))
     with torch.no_grad(), mock.patch.object(FastSpeech2Align, "_wait_phase1", side_effect=AssertionError("host waited")), \
             mock.patch.object(torch.cuda.Event, "synchronize", side_effect=AssertionError("host waited")), \
             mock.patch.object(torch.cuda, "synchronize", side_effect=AssertionError("host waited")):
-        cap = m(*args, max_mel_len=T)   # would raise if the forward waited for phase 1 in any way
-    assert m.check_status() == [0] * len(z["in_src_lens"])
+        cap = m(*args, max_mel_len=T, async_status=True)   # would raise if the forward waited for phase 1 in any way
+    assert cap.check() == [0] * nb and m.check_status(cap) == [0] * nb and m.check_status() == [0] * nb
+    assert len(cap) == 12 and isinstance(cap, tuple)
     for i in (0, 1, 2, 3, 4, 5, 6, 7, 9):
         assert torch.equal(cap[i], base[i]), NAMES[i]
-    # a larger capacity: same as the synchronous padded run
+    # a larger capacity: same as the synchronous padded run — through a callable and through a plain int
     with torch.no_grad():
-        cap9 = m(*args, max_mel_len=T + 9)
+        cap9 = m(*args, max_mel_len=T + 9, async_status=True)
         ref9 = m(*args, max_mel_len=lambda t: int(t) + 9)
-    assert all(torch.equal(cap9[i], ref9[i]) for i in (0, 1, 2, 3, 7, 9)) and m.check_status() == [0] * len(z["in_src_lens"])
+        int9 = m(*args, max_mel_len=T + 9)  # an int WITHOUT the opt-in is synchronous
+    assert all(torch.equal(cap9[i], ref9[i]) and torch.equal(int9[i], ref9[i]) for i in (0, 1, 2, 3, 7, 9)) and cap9.check() == [0] * nb
     # too small a capacity: every utterance longer than it is reported, the others are bit-identical to a run at that padding
     lens = base[9].cpu().numpy()
     Tcut = int(np.sort(lens)[-2]) if len(lens) > 1 and np.sort(lens)[-2] < T else T - 1
     with torch.no_grad():
-        cut = m(*args, max_mel_len=Tcut)
-    words = m.last_status.cpu().numpy()
+        cut = m(*args, max_mel_len=Tcut, async_status=True)
+        ok_again = m(*args, max_mel_len=T, async_status=True)  # a later forward must not overwrite the earlier call's status
+    words = cut.status.cpu().numpy()
     assert np.array_equal(words & _lib.STATUS_TRUNCATED, (lens > Tcut).astype(np.int32)) and cut[0].shape[1] == Tcut
     assert torch.isfinite(cut[1]).all() and torch.equal(cut[9], base[9])
     with pytest.raises(ValueError, match="cut off"):
-        m.check_status()
-    # a bad token id: the synchronous path raises IndexError on the spot, capacity mode through check_status()
+        cut.check()
+    assert ok_again.check() == [0] * nb
+    # ... while the same int WITHOUT the opt-in raises on the spot, like every synchronous forward
+    with pytest.raises(ValueError, match="smaller than the longest"):
+        m(*args, max_mel_len=Tcut)
+    with pytest.raises(ValueError, match="async_status"):
+        m(*args, async_status=True)
+    # a bad token id: the synchronous paths raise IndexError on the spot, capacity mode through the output's status
     bad = z["texts"].copy()
     bad[0, 0] = 100000
     with pytest.raises(IndexError):
         m(args[0], dev(bad), args[2], args[3])
-    with torch.no_grad():
-        m(args[0], dev(bad), args[2], args[3], max_mel_len=T)
-    assert m.last_status.cpu().numpy()[0] & _lib.STATUS_BAD_TOKEN
     with pytest.raises(IndexError):
-        m.check_status()
+        m(args[0], dev(bad), args[2], args[3], max_mel_len=T)
+    with torch.no_grad():
+        ob = m(args[0], dev(bad), args[2], args[3], max_mel_len=T, async_status=True)
+    assert ob.status.cpu().numpy()[0] & _lib.STATUS_BAD_TOKEN
+    with pytest.raises(IndexError):
+        ob.check()
     # the C-ABI refuses to run without a status buffer (a C caller cannot truncate silently)
     rc = m._lib.ns_forward_mel(m._h, 1, 1, 1, None, 1.0, 1.0, None, None, None, None, 0, None, None, None, None, None, None, None)
     assert rc != 0 and b"status" in m._lib.ns_last_error()
     m.packed_rows = True
+
+
+def test_fresh_workspace_after_a_length_hint_is_large_enough():
+    """ns_decoder_ws_bytes is not monotonic in T (a shorter mel axis can take attention's split-key path, whose partials
+    outweigh the rest), and the synchronous forward sizes phase 2's scratch BEFORE it knows T, from the previous forward of
+    the same shape plus slack.  With a fresh workspace (new stream, release_workspaces(), LRU eviction) that guess alone was
+    too small: B=32 at T ~ 120 needed 119 MB against 81 MB allocated and forward() raised 'workspace too small'."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    cfg = wl.model_config("ljspeech")
+    m = FastSpeech2Align(wl.preprocess_config(), cfg).to("cuda:0").eval()
+    m.load_state_dict(wl.synth_state_dict(cfg, seed=0, frames_per_phoneme=7.0))
+    hit = 0
+    for B, L in ((32, 15), (8, 120), (16, 48)):
+        sp, tx, ln, Lm = wl.synth_inputs(B, L, seed=3)
+        a = [dev(x) for x in (sp, tx, ln)]
+        with torch.no_grad():
+            first = m(a[0], a[1], a[2], Lm)
+            T = int(first[0].shape[1])
+            Tc = T + max(8, T >> 3)
+            need_T, need_Tc = m._ws_bytes("dec", B, L, T), m._ws_bytes("dec", B, L, Tc)
+            hit += int(need_T > int(need_Tc * 1.25) + 256)  # the case that used to raise
+            m.release_workspaces()
+            again = m(a[0], a[1], a[2], Lm)          # hint path, fresh scratch
+            s2 = torch.cuda.Stream()
+            with torch.cuda.stream(s2):               # and on a stream that has never been used
+                third = m(a[0], a[1], a[2], Lm)
+            torch.cuda.synchronize()
+        assert torch.equal(first[1], again[1]) and torch.equal(first[1], third[1]) and torch.equal(first[9], again[9])
+    print(f"shapes whose exact-T workspace exceeds the hinted allocation: {hit} of 3")
 
 
 def test_rejected_state_dict_leaves_the_loaded_model_usable():
