@@ -541,15 +541,10 @@ static int gemm_ln(const float* X, int ldx, const float* W, const float* bias, c
     NS_HIP(launch_layernorm(tmp, g, b, Y, M, N, S, lens, st, cur_rm()));
     return 0;
   }
-  if (fuse_row_epilogue(M, N, Cin)) {
-    // large launches: the full-row tile — unless its steps of 256 tiles fit the row count badly and 64x64 tiles with the
-    // ticketed epilogue are cheaper (the step-aware plan, gemm_conv.hip conv_gemm_ln_form; same bits either way)
-    if (!Wb3 && conv_gemm_ln_form(M, N, Cin, KW) == LN_TICKET && (e.ticket = sc.take_tickets(conv_gemm_ticket_ints(M))) != nullptr) {
-      e.y_out = Y;
-      return gemm(X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st, &e, EPI_LN);
-    }
-    return gemm(X, ldx, W, bias, resid, N, Y, N, M, N, Cin, KW, S, act, st, &e, EPI_LN, Wb3);
-  }
+  // (64x64 tiles with the ticketed epilogue in place of the full-row tile when its steps of 256 tiles fit the row count badly
+  //  were measured in round 4 and lose: at 572 workgroups the last arrivers' row work costs +12 us for a LayerNorm and +25 us
+  //  for a predictor tail, more than the finer steps save — B = 9: conv+LN 57 vs 56 us, conv+tail 80-86 vs 62, w_2 70.7 vs 70)
+  if (fuse_row_epilogue(M, N, Cin)) return gemm(X, ldx, W, bias, resid, N, Y, N, M, N, Cin, KW, S, act, st, &e, EPI_LN, Wb3);
   if (conv_gemm_ticket_ok(M, N, Cin) && (e.ticket = sc.take_tickets(conv_gemm_ticket_ints(M))) != nullptr) {
     e.y_out = Y;
     return gemm(X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st, &e, EPI_LN);
@@ -658,11 +653,8 @@ static int predictor(const ns_model* m, const PredW& w, const float* x, const lo
   e.ln_g = m->P(w.ln2_g); e.ln_b = m->P(w.ln2_b); e.lens = lens; e.wlin = m->P(w.lin_w); e.blin = m->P(w.lin_b); e.pred = pred;
   e.control = control; e.target = target; e.bins = bins; e.n_edges = c.n_bins - 1; e.emb = emb; e.x_in = x; e.pos = pos; e.x_out = x_out;
   e.D = w.cin;
-  if (fuse_row_epilogue(M, F, F)) {
-    if (conv_gemm_ln_form(M, F, F, c.vp_kernel) == LN_TICKET && (e.ticket = sc.take_tickets(conv_gemm_ticket_ints(M))) != nullptr)
-      return gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st, &e, EPI_LN_PRED);
+  if (fuse_row_epilogue(M, F, F))
     return gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, nullptr, F, M, F, F, c.vp_kernel, S, ACT_RELU, st, &e, EPI_LN_PRED);
-  }
   if (conv_gemm_ticket_ok(M, F, F) && (e.ticket = sc.take_tickets(conv_gemm_ticket_ints(M))) != nullptr)
     return gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st, &e, EPI_LN_PRED);
   NS_TRY(gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st));

@@ -35,6 +35,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int ATT_STRIP_SPLIT_MAX = 8;  // workgroups sharing one 32-query strip's key axis (k_attention_strip)
 
+// One step of merging key-range partials, out += O_i * w_i / l += l_i * w_i, with the multiply-adds spelled out: the last
+// arriver of k_attention_strip and k_attention_merge must produce the same bits from the same partials (the two-launch form
+// of a ticketed merge, ns_config.row_epilogue), whatever hipcc would contract in either kernel.
+__device__ __forceinline__ f32x4 merge_fma(f32x4 o, float w, f32x4 acc) {
+#pragma clang fp contract(off)
+  return f32x4{__builtin_fmaf(o[0], w, acc[0]), __builtin_fmaf(o[1], w, acc[1]), __builtin_fmaf(o[2], w, acc[2]), __builtin_fmaf(o[3], w, acc[3])};
+}
+
 template <int DK>
 __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, const long long* __restrict__ lens,
                                                     int S_grid, int d, float c_scale, float* __restrict__ out, int nsplit,
@@ -589,9 +597,9 @@ __global__ __launch_bounds__(256) void k_attention_strip(const float* __restrict
   for (int s2 = 0; s2 < ATT_STRIP_SPLIT_MAX; ++s2) {
     if (s2 < nsplit) {  // wave-uniform
       const float w2 = __builtin_amdgcn_exp2f(ml2[s2][0] - mx_use);
-      l += ml2[s2][1] * w2;
+      l = __builtin_fmaf(ml2[s2][1], w2, l);
 #pragma unroll
-      for (int pj = 0; pj < NDB; ++pj) acc[pj] += op[s2][pj] * w2;
+      for (int pj = 0; pj < NDB; ++pj) acc[pj] = merge_fma(op[s2][pj], w2, acc[pj]);
     }
   }
   if (q >= S) return;
@@ -618,8 +626,8 @@ __global__ __launch_bounds__(256) void k_attention_merge(const float* __restrict
     for (int sp = 0; sp < nsplit; ++sp) {
       const size_t row = (size_t)sp * M + m;
       const float w = __builtin_amdgcn_exp2f(mlpart[(row * H + hd) * 2] - m_use);
-      l += mlpart[(row * H + hd) * 2 + 1] * w;
-      acc += *reinterpret_cast<const f32x4*>(opart + row * d + c) * w;
+      l = __builtin_fmaf(mlpart[(row * H + hd) * 2 + 1], w, l);
+      acc = merge_fma(*reinterpret_cast<const f32x4*>(opart + row * d + c), w, acc);
     }
     const float inv = 1.0f / l;  // no valid key at all -> 0 * inf = NaN, as the reference
     *reinterpret_cast<f32x4*>(out + (size_t)m * d + c) = acc * inv;

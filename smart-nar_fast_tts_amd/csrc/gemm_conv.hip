@@ -470,8 +470,13 @@ static constexpr TileModel kTile[N_TILES] = {
 static long tile_wgs(int t, long M, int N) { return ((M + kTile[t].bm - 1) / kTile[t].bm) * ((N + kTile[t].bn - 1) / kTile[t].bn); }
 static float tile_time(int t, long M, int N, int chunks) {
   const long steps = (tile_wgs(t, M, N) + 255) / 256;
+  const float a = kTile[t].a0 + kTile[t].a1 * chunks, b = kTile[t].b0 + kTile[t].b1 * chunks;
+  // the 4-wave tiles re-read the weight matrix once per 32 / 64 rows: alone in a partial step they run at the rate above,
+  // in launches of many steps the fabric slows every step after the first by ~15 % (forward traces: k=9 2280 workgroups
+  // 365 us, k=5 512->512 2148 workgroups 383 us, QKV 3222 workgroups 74 us; the lab loop on a quiet chip showed 5 %)
+  const float more = (t == T64N || t == T32) ? 1.15f : 1.0f;
   // between near-ties the taller tile (fewer passes over the weights, settled by forward A/B runs in round 3) keeps the launch
-  return (kTile[t].a0 + kTile[t].a1 * chunks + (kTile[t].b0 + kTile[t].b1 * chunks) * (float)steps) * (1.0f + 0.01f * (float)t);
+  return (a + b + b * more * (float)(steps - 1)) * (1.0f + 0.01f * (float)t);
 }
 static hipError_t launch_tile(int t, const ConvGemm& p, hipStream_t st, const LaunchTiming* tm) {
   switch (t) {
@@ -509,16 +514,6 @@ static RowPlan plan_rows(long M, int N, int chunks) {
     }
   }
   return best;
-}
-
-// full-row tile (32 rows x N, one step per 256 tiles) against 64x64 tiles with the ticketed last-arriver epilogue (+ ~3 us)
-int conv_gemm_ln_form(int M, int N, int Cin, int KW) {
-  if (!launch_planner_enabled() || !conv_gemm_ticket_ok(M, N, Cin)) return LN_FULL_ROW;
-  const int chunks = KW * (Cin / 32), nv = N / 256;
-  const long full_steps = (((long)M + 31) / 32 + 255) / 256;
-  const float full = 5.0f + 0.1f * chunks + (1.9f + 0.95f * chunks) * (float)nv * (float)full_steps;
-  const float tick = tile_time(T64N, M, N, chunks) / (1.0f + 0.01f * T64N) + 3.0f;
-  return tick < 0.95f * full ? LN_TICKET : LN_FULL_ROW;
 }
 
 static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bool allow_split, const LaunchTiming* tm);

@@ -71,10 +71,6 @@ struct ConvGemm {
 // A plan of several launches gets `start` on its first and `stop` on its last kernel.  nullptr / {nullptr, nullptr} = untimed.
 struct LaunchTiming { hipEvent_t start, stop; };
 hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st, const LaunchTiming* tm = nullptr);
-// How a GEMM with a row epilogue (LayerNorm / predictor tail over whole N-wide rows) is best launched for M rows — the step-aware
-// planner's answer (gemm_conv.hip): the 32-row full-row tile, or narrower tiles with the ticketed last-arriver epilogue.
-enum LnForm : int { LN_FULL_ROW = 0, LN_TICKET = 1 };
-int conv_gemm_ln_form(int M, int N, int Cin, int KW);
 // NS_PLAN=0 in the environment: the round-3 one-tile-per-launch rules (A/B runs of the planner; read once)
 bool launch_planner_enabled();
 // opt-in "bf16x3" precision mode (gemm_bf16x3.hip): same contraction from an exact 3-way bf16 split of both operands

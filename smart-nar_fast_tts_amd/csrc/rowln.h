@@ -39,6 +39,17 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 constexpr float LN_EPS = 1e-5f;  // torch.nn.LayerNorm default
 
+// The row arithmetic below is written with EXPLICIT fused multiply-adds under `fp contract(off)`: the same source runs inside
+// several kernels (the row kernels, the full-row GEMM epilogue, the ticketed epilogue with its batched rows) and hipcc decides
+// contraction per instantiation — left to it, the ticketed predictor tail and k_ln_linear_embed differed in the last bit of
+// log_d / pitch / energy (round 4, tests/test_gpu_stress.py: fused vs two_launch).  With the operations spelled out every user
+// produces the same bits by construction, not by the optimiser's mood.
+// y = (v - mean) * rstd * g + b as ((v - mean) * rstd) * g + b with ONE rounding for the last multiply-add
+__device__ __forceinline__ float ln_affine(float v, float mean, float rstd, float g, float b) {
+#pragma clang fp contract(off)
+  return __builtin_fmaf((v - mean) * rstd, g, b);
+}
+
 // torch.bucketize(v, bins, right=False) (model/modules.py:86-88,97-99), wave-cooperative: the index is the number
 // of edges e with !(e >= v) — for sorted edges that is the first i with bins[i] >= v, and NaN maps to n_edges.
 __device__ __forceinline__ int wave_bucketize(const float* __restrict__ bins, int n_edges, float v, int lane) {
@@ -51,6 +62,7 @@ __device__ __forceinline__ int wave_bucketize(const float* __restrict__ bins, in
 // Two-pass (mean, then centred sum of squares), biased variance, as nn.LayerNorm.
 template <int NV>
 __device__ __forceinline__ void ln_moments(const f32x4 (&v)[NV], int C, int lane, float& mean, float& rstd) {
+#pragma clang fp contract(off)
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -63,7 +75,7 @@ __device__ __forceinline__ void ln_moments(const f32x4 (&v)[NV], int C, int lane
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float dlt = v[i][e] - mean;
-        q += dlt * dlt;
+        q = __builtin_fmaf(dlt, dlt, q);
       }
     }
   }
@@ -83,7 +95,7 @@ __device__ __forceinline__ void ln_store(const f32x4 (&v)[NV], int C, int lane, 
       const f32x4 bb = *reinterpret_cast<const f32x4*>(bta + c);
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+      for (int e = 0; e < 4; ++e) o[e] = ln_affine(v[i][e], mean, rstd, gg[e], bb[e]);
       *reinterpret_cast<f32x4*>(y + c) = o;
     }
   }
@@ -101,6 +113,7 @@ __device__ __forceinline__ void ln_store(const f32x4 (&v)[NV], int C, int lane, 
 // value part: pred[m] (returned too)
 template <int NV>
 __device__ __forceinline__ float predictor_row_value(const f32x4 (&v)[NV], int C, int lane, const RowEpilogue& e, int m, bool masked, bool store = true) {
+#pragma clang fp contract(off)
   float mean, rstd;
   ln_moments<NV>(v, C, lane, mean, rstd);
   float dot = 0.f;
@@ -112,7 +125,7 @@ __device__ __forceinline__ float predictor_row_value(const f32x4 (&v)[NV], int C
       const f32x4 bb = *reinterpret_cast<const f32x4*>(e.ln_b + c);
       const f32x4 ww = *reinterpret_cast<const f32x4*>(e.wlin + c);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) dot += ((v[i][k] - mean) * rstd * gg[k] + bb[k]) * ww[k];
+      for (int k = 0; k < 4; ++k) dot = __builtin_fmaf(ln_affine(v[i][k], mean, rstd, gg[k], bb[k]), ww[k], dot);
     }
   }
   float pv = wave_sum(dot) + e.blin[0];
@@ -164,7 +177,7 @@ __device__ __forceinline__ void row_batch_finish(f32x4 (&v)[R][NV], const int (&
 #pragma unroll
       for (int i = 0; i < NV; ++i)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[j][i][k] = masked[j] ? 0.f : (v[j][i][k] - mean) * rstd * lng[i][k] + lnb[i][k];  // == ln_store's expression; masked_fill(mask, 0)
+        for (int k = 0; k < 4; ++k) v[j][i][k] = masked[j] ? 0.f : ln_affine(v[j][i][k], mean, rstd, lng[i][k], lnb[i][k]);  // ln_store's expression; masked_fill(mask, 0)
     }
 #pragma unroll
     for (int j = 0; j < R; ++j) {

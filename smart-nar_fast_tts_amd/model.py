@@ -8,6 +8,7 @@ unchanged.  All tensor math happens in the HIP kernels behind the C-ABI
 """
 from __future__ import annotations
 
+import builtins
 import contextlib
 import ctypes as C
 import functools
@@ -139,6 +140,11 @@ class FastSpeech2Align:
         # phase 2 of a synchronous forward runs on packed rows (variable-length batches: include/nar_fs2.h
         # ns_forward_mel_packed); model_config["padded_rows"] = "dense" or NS_PACKED=0 keeps the reference's padded grid
         self.packed_rows = model_config.get("padded_rows", "packed" if os.environ.get("NS_PACKED", "1") != "0" else "dense") == "packed"
+        # EXTENSION key: "separate" returns individually-owned tensors (one clone each) instead of views cut from the forward's two
+        # output blocks — for callers that torch.save() single outputs (a view would drag its whole block into the file)
+        self.outputs = model_config.get("outputs", "views")
+        if self.outputs not in ("views", "separate"):
+            raise ValueError("model_config['outputs'] must be 'views' or 'separate'")
         self._t_hint = {}         # (B, L) -> T of the last synchronous forward of that shape (capacity guess for the next one)
         self._ws_need = {}        # (kind, B, L, T) -> bytes (ns_*_ws_bytes is a pure function of the config and these)
         self._sd = OrderedDict()  # host copy of what load_state_dict received (for state_dict() / .to())
@@ -203,6 +209,75 @@ class FastSpeech2Align:
 
     def state_dict(self):
         return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in self._sd.items())
+
+    # What code that introspects an nn.Module finds (model/fastspeech2_align.py:13-28, utils/model.py:31-35 counts parameters):
+    # HOST copies of what load_state_dict received — the device copy is one packed arena (tap-major convolutions, fused QKV,
+    # BatchNorm folded into the PostNet), not per-parameter tensors, so writing into these does not change the model; call
+    # load_state_dict() for that.  Buffers are what nn.Module keeps out of parameters(): the BatchNorm running statistics.
+    @staticmethod
+    def _is_buffer(key: str) -> bool:
+        return key.endswith((".running_mean", ".running_var", ".num_batches_tracked"))
+
+    def named_parameters(self, prefix: str = "", recurse: bool = True):
+        self._ensure_host_copy()
+        for k, v in self._sd.items():
+            if not self._is_buffer(k):
+                yield (prefix + ("." if prefix else "") + k, torch.from_numpy(np.array(v)).requires_grad_(False))
+
+    def parameters(self, recurse: bool = True):
+        for _, p in self.named_parameters():
+            yield p
+
+    def named_buffers(self, prefix: str = "", recurse: bool = True):
+        self._ensure_host_copy()
+        for k, v in self._sd.items():
+            if self._is_buffer(k):
+                yield (prefix + ("." if prefix else "") + k, torch.from_numpy(np.array(v)))
+
+    def buffers(self, recurse: bool = True):
+        for _, b in self.named_buffers():
+            yield b
+
+    def _ensure_host_copy(self):
+        if not self._sd and self._adopted:
+            raise RuntimeError("this model's weights arrived as packed arena bytes (adopt_arena): there is no per-parameter host copy; "
+                               "introspect the rank that called load_state_dict()")
+        if not self._sd and self._stats is not None:
+            self._sd = OrderedDict(wl.default_init_state_dict(self.model_config, self._stats))  # what the reference constructor holds
+
+    def modules(self):
+        """The native forward is one object: there are no sub-modules to walk (hooks on sub-modules have nothing to attach to)."""
+        yield self
+
+    def named_modules(self, memo=None, prefix: str = "", remove_duplicate: bool = True):
+        yield prefix, self
+
+    def children(self):
+        return iter(())
+
+    def named_children(self):
+        return iter(())
+
+    def float(self):
+        return self  # float32 is what the path computes in
+
+    def _no_cast(self, what):
+        raise NotImplementedError(f"{what}: this path computes in float32 only (the reference's arithmetic, mel max-abs < 1e-3); "
+                                  "the opt-in bf16x3 matrix mode is model_config['matmul'] = 'bf16x3', not a dtype cast")
+
+    def half(self):
+        self._no_cast("half()")
+
+    def bfloat16(self):
+        self._no_cast("bfloat16()")
+
+    def double(self):
+        self._no_cast("double()")
+
+    def register_forward_hook(self, *a, **k):
+        raise NotImplementedError("forward hooks: wrap forward() instead — the 12-tuple is the only tensor boundary of the native forward")
+
+    register_forward_pre_hook = register_forward_hook
 
     def _stage(self, key: str, a: np.ndarray):
         """Hand one (already validated) entry to the native staging area."""
@@ -381,7 +456,7 @@ class FastSpeech2Align:
     def __call__(self, *args, **kwargs):
         return self.forward(*args, **kwargs)
 
-    SPIN_US = float(os.environ.get("NS_SPIN_US", "300"))  # busy-wait budget for the mid-forward hand-over, then block
+    SPIN_US = builtins.float(os.environ.get("NS_SPIN_US", "300"))  # (builtins.: the class defines a float() method above)  # busy-wait budget for the mid-forward hand-over, then block
 
     def _wait_phase1(self, dev):
         """Wait for phase 1 on the launch stream.  A blocking synchronize sleeps and costs ~50 us of wake-up latency per
@@ -561,7 +636,11 @@ class FastSpeech2Align:
             mel, post, mel_masks = blk2.view("mel"), blk2.view("post"), blk2.view("mel_masks")
             p_pred = blk2.view("p_pred") if p_frame else blk1.view("p_pred")
             e_pred = blk2.view("e_pred") if e_frame else blk1.view("e_pred")
-        out = ForwardOutput((mel, post, p_pred, e_pred, log_d, d_rounded, src_masks, mel_masks, src_lens, out_mel_lens, None, None),
-                            status=status, n_vocab=self._cfg.n_vocab)
+        items = (mel, post, p_pred, e_pred, log_d, d_rounded, src_masks, mel_masks, src_lens, out_mel_lens, None, None)
+        if self.outputs == "separate":  # own storage per tensor (src_lens is the caller's own tensor, passed through like the reference does)
+            with torch.cuda.stream(torch.cuda.current_stream(dev)):
+                items = tuple(t.clone() if (torch.is_tensor(t) and i != 8) else t for i, t in enumerate(items))
+                status = status.clone()
+        out = ForwardOutput(items, status=status, n_vocab=self._cfg.n_vocab)
         self._last_out = out
         return out

@@ -28,7 +28,12 @@ def main():
     ap.add_argument("--matmul", choices=["fp32", "bf16x3"], default="fp32", help="also exercise the opt-in bf16x3 mode")
     ap.add_argument("--big", action="store_true", help="batches up to 24 utterances: B*T rows beyond 6400, where the full-row "
                     "GEMM + LayerNorm epilogue (and, with --matmul bf16x3, the split-bf16 tiles) take over from the small-grid ladder")
-    args = ap.parse_args()
+    run(ap.parse_args())
+
+
+def run(args, max_seconds=None):
+    """One fuzz run; returns {"checked", "skipped", "packed", "worst"}.  ``args``: iters, seed, matmul, big (an argparse
+    namespace or anything with those attributes).  ``max_seconds`` ends the run early (the -m gpu slice is time-boxed)."""
     import smart_nar_fast_tts_amd.workload as wl
     from oracle import fs2_oracle as orc
     from smart_nar_fast_tts_amd.model import FastSpeech2Align
@@ -40,6 +45,8 @@ def main():
     cache = {}
     t_start = time.time()
     for it in range(args.iters):
+        if max_seconds is not None and time.time() - t_start > max_seconds:
+            break
         cname = str(rs.choice(["tiny", "tiny", "tiny512", "tiny_h4"]))
         fpp = float(rs.choice([1.0, 2.0, 4.0, 8.0]))
         plevel = str(rs.choice(["frame_level", "frame_level", "phoneme_level"]))
@@ -95,6 +102,7 @@ def main():
         if (it + 1) % 25 == 0:
             print(f"[{it + 1}/{args.iters}] checked {checked} skipped {skipped} worst {worst} ({time.time() - t_start:.0f} s)", flush=True)
     print(f"FUZZ OK: {checked} cases checked ({packed} of them with phase 2 on packed rows), {skipped} skipped (duration on a rounding boundary / empty), worst errors {worst}")
+    return {"checked": checked, "skipped": skipped, "packed": packed, "worst": worst}
 
 
 if __name__ == "__main__":

@@ -315,3 +315,40 @@ def test_output_blocks_are_one_allocation_with_aligned_views():
     blk.view("post").fill_(2.0)
     assert float(blk.view("mel").sum()) == 3 * 33 * 80 and float(blk.view("post").sum()) == 2 * 3 * 33 * 80  # (no aliasing)
     assert blk.ptr("absent").value in (None, 0)
+
+
+def test_module_introspection_surface():
+    """What code that walks an nn.Module finds on the drop-in (model/fastspeech2_align.py:13-28; utils/model.py:31-35 counts
+    parameters): parameters() / named_parameters() over the host copies, BatchNorm running statistics as buffers, modules()
+    = the object itself, float() a no-op and the casts that cannot be honoured raising clearly."""
+    import torch
+
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align, ForwardOutput
+
+    cfg = wl.model_config("tiny")
+    m = FastSpeech2Align(wl.preprocess_config(), cfg)
+    sd = wl.synth_state_dict(cfg)
+    m.load_state_dict(sd)  # (no GPU here: the state dict is validated and kept on the host, uploaded on first use of a device)
+    named = dict(m.named_parameters())
+    bufs = dict(m.named_buffers())
+    is_buf = lambda k: k.endswith((".running_mean", ".running_var", ".num_batches_tracked"))  # noqa: E731
+    assert set(named) == {k for k in m._sd if not is_buf(k)} and set(bufs) == {k for k in m._sd if is_buf(k)}
+    assert len(bufs) == 2 * 5 and all(torch.is_tensor(p) and p.dtype == torch.float32 and not p.requires_grad for p in named.values())
+    # utils/model.py:31-35 get_param_num: sum(param.numel() for param in model.parameters())
+    assert sum(p.numel() for p in m.parameters()) == sum(int(np.prod(np.shape(v))) for k, v in m._sd.items() if not is_buf(k))
+    np.testing.assert_array_equal(named["mel_linear.weight"].numpy(), np.asarray(sd["mel_linear.weight"], dtype=np.float32))
+    assert list(m.modules()) == [m] and list(m.children()) == [] and dict(m.named_modules()) == {"": m}
+    assert m.float() is m and m.eval() is m
+    for cast in (m.half, m.bfloat16, m.double):
+        with pytest.raises(NotImplementedError, match="float32"):
+            cast()
+    with pytest.raises(NotImplementedError, match="wrap forward"):
+        m.register_forward_hook(lambda *a: None)
+    with pytest.raises(ValueError, match="outputs"):
+        FastSpeech2Align(wl.preprocess_config(), dict(cfg, outputs="copies"))
+    # the forward's return type is the reference's 12-tuple for every positional consumer
+    out = ForwardOutput(tuple(range(12)), status=None)
+    assert isinstance(out, tuple) and len(out) == 12 and out[9] == 9 and out.check() == [] and tuple(out) == tuple(range(12))
+    a, b, *rest = out
+    assert (a, b) == (0, 1) and len(rest) == 10

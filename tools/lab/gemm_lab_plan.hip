@@ -56,7 +56,7 @@ static void stair(const ConvGemm& base, const char* name) {
 
 int main() {
   struct Shape { const char* name; int Cin, KW, N; } shapes[] = {
-      {"k9 256->1024", 256, 9, 1024}, {"k5 512->512", 512, 5, 512}, {"k1 256->768", 256, 1, 768}, {"k1 1024->256", 1024, 1, 256}, {"k3 256->256", 256, 3, 256}};
+      {"k9 256->1024", 256, 9, 1024}, {"k5 512->512", 512, 5, 512}};
   const int MAXM = 36000;
   for (auto& s : shapes) {
     size_t nx = (size_t)MAXM * s.Cin, nw = (size_t)s.N * s.KW * s.Cin, ny = (size_t)MAXM * s.N;
@@ -71,6 +71,7 @@ int main() {
     ConvGemm p; memset(&p, 0, sizeof(p)); p.X = dx; p.ldx = s.Cin; p.W = dw; p.bias = db; p.Y = dy; p.ldy = s.N;
     p.M = MAXM; p.N = s.N; p.Cin = s.Cin; p.KW = s.KW; p.pad = (s.KW - 1) / 2; p.S = MAXM; p.act = ACT_RELU;
     printf("== %s: workgroups:us(TFLOP/s)\n", s.name);
+    if (getenv("NS_LAB_STAIRS")) {
     if (s.N >= 512) stair<256, 256, 32, 1, 8, 2>(p, s.name);
     if (s.N >= 256) stair<128, 256, 32, 1, 4, 4>(p, s.name);
     if (s.N >= 256) stair<64, 256, 32, 1, 2, 4>(p, s.name);
@@ -80,6 +81,7 @@ int main() {
     stair<32, 128, 32, 1, 1, 4>(p, s.name);
     stair<32, 64, 32, 1, 1, 2>(p, s.name);
     stair<32, 128, 64, 1, 1, 4>(p, s.name);
+    }
 
     if (s.KW > 1) {
       // main + remainder: B = 9 rows (9090) as 8192 rows of 64x256 tiles + 898 rows on a finer tile
@@ -100,6 +102,23 @@ int main() {
         const float a32 = time_us([&] { CK((launch_t<64, 256, 32, 1, 2, 4>(pm, 0))); CK((launch_any<32, 128, 32, 1, 1, 4>(pr, 0, hipExtAnyOrderLaunch))); });
         // remainder FIRST (small tiles spread over the chip), main behind it without a barrier
         const float b32 = time_us([&] { CK((launch_t<32, 128, 32, 1, 1, 4>(pr, 0))); CK((launch_any<64, 256, 32, 1, 2, 4>(pm, 0, hipExtAnyOrderLaunch))); });
+        // the remainder on a forked second stream, so that it co-resides with the main launch (fork: event on st0 -> wait on st1;
+        // join: event on st1 -> wait on st0).  Main = the 128x256 tile (one workgroup per CU, 96 KB LDS: a 32 KB 64x64 workgroup fits beside it)
+        static hipStream_t s1 = nullptr; static hipEvent_t ef, ej;
+        if (!s1) { CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ej, hipEventDisableTiming)); }
+        ConvGemm pm128 = row_range(p, 0, 8192 / ((s.N + 255) / 256) * ((s.N + 255) / 256) == 0 ? 8192 : (256 / ((s.N + 255) / 256)) * 128);
+        ConvGemm pr128 = row_range(p, pm128.M, rem);
+        const float m128 = time_us([&] { CK((launch_t<128, 256, 32, 1, 4, 4>(pm128, 0))); });
+        const float ser128 = time_us([&] { CK((launch_t<128, 256, 32, 1, 4, 4>(pm128, 0))); CK((launch_t<64, 64, 32, 1, 2, 2>(pr128, 0))); });
+        const float fj128 = time_us([&] {
+          CK(hipEventRecord(ef, 0)); CK(hipStreamWaitEvent(s1, ef, 0));
+          CK((launch_t<64, 64, 32, 1, 2, 2>(pr128, s1))); CK(hipEventRecord(ej, s1));
+          CK((launch_t<128, 256, 32, 1, 4, 4>(pm128, 0))); CK(hipStreamWaitEvent(0, ej, 0)); });
+        const float fj64 = time_us([&] {
+          CK(hipEventRecord(ef, 0)); CK(hipStreamWaitEvent(s1, ef, 0));
+          CK((launch_t<64, 64, 32, 1, 2, 2>(pr, s1))); CK(hipEventRecord(ej, s1));
+          CK((launch_t<64, 256, 32, 1, 2, 4>(pm, 0))); CK(hipStreamWaitEvent(0, ej, 0)); });
+        printf("  fork/join: main 128x256 (%d rows) alone %.1f, + 64x64 rem serial %.1f, forked %.1f | main 64x256 + 64x64 rem forked %.1f\n", pm128.M, m128, ser128, fj128, fj64);
         printf("  main %d rows (64x256) + rem %d: plan-now %.1f | main %.1f, rem alone 64x128 %.1f 32x128 %.1f 32x256 %.1f 32x64 %.1f | serial +64x128 %.1f +32x128 %.1f | any-order +64x128 %.1f +32x128 %.1f | rem-first any-order %.1f\n",
                main_rows, rem, t_all, t_main, t_r64, t_r32, t_r32w, t_r3264, s64, s32, a64, a32, b32);
       }
