@@ -317,13 +317,17 @@ def main():
         for _ in range(args.warmup):
             out = step()
         fence()
-        model.profile_dominant_kernel(True)
+        # the dominant kernel is timed on every PROF_EVERY-th forward of the timed region: a timed launch costs its stream
+        # ~5 us (its dispatch packet carries a completion signal with timestamps), 20 us per forward if all four were timed
+        PROF_EVERY = 5
+        model.profile_slots(())
         # per-step spread without extra syncs: one event per step on the launch stream, read after the closing fence
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if streams is None else None
         t0 = time.perf_counter()
         if marks:
             marks[0].record()
         for i in range(args.steps):
+            model.profile_slots((0,) if i % PROF_EVERY == 0 else (), keep=True)
             out = step()
             if marks:
                 marks[i + 1].record()
@@ -419,8 +423,8 @@ def main():
         sus_max = float(sstat[0])
         quarter = max(1, n_sus // 4)
         order = [ev[i].elapsed_time(ev[i + 1]) for i in range(n_sus)]
-        sustained = {"steps": n_sus, "seconds": round(sus_max, 3), "ms_per_step": round(sus_max / n_sus * 1e3, 4),
-                     "value": round(frames_total * n_sus / sus_max, 1), "unit": "frames/s",
+        sustained = {"steps": n_sus, "seconds": round(sus_max, 3), "ms_per_step": sus_max / n_sus * 1e3,
+                     "value": frames_total * n_sus / sus_max, "unit": "frames/s",
                      "step_ms": {"p50": round(sms[n_sus // 2], 3), "p99": round(sms[min(n_sus - 1, int(n_sus * 0.99))], 3),
                                  "min": round(sms[0], 3), "max": round(sms[-1], 3),
                                  "mean_first_quarter": round(sum(order[:quarter]) / quarter, 3),
@@ -485,7 +489,8 @@ def main():
                      "rocprof_avg_launch_us": rocprof_us,
                      "frac_of_measured_peak": round(achieved_tflops / F32_MFMA_MEASURED_TFLOPS, 4),
                      "launches": int(k_launches), "avg_launch_ms": round(k_ms / max(k_launches, 1), 4),
-                     "share_of_step_time": round((k_ms * 1e-3) / elapsed if elapsed > 0 else 0.0, 3),
+                     "launches_timed": f"every launch of every {PROF_EVERY}th forward of the timed region (HIP events on the dispatch packets)",
+                     "share_of_step_time": round((k_ms / len(range(0, args.steps, PROF_EVERY))) / (elapsed / args.steps * 1e3) if elapsed > 0 else 0.0, 3),
                      "geometry": geom},
     }
     if sustained:
@@ -590,27 +595,35 @@ def main():
         rl[0] = L
         rs_, rt_, rln_, _ = wl.synth_inputs(B_shard, L, seed=0, src_lens=rl)
         ra = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (rs_, rt_, rln_)]
+        rln_host = torch.from_numpy(np.ascontiguousarray(rln_))  # src_lens as a host tensor: phase 1 packs too (nar_fs2.h ns_forward_durations_packed)
         vl = {}
         keep = model.packed_rows
         try:
-            for mode in ("packed", "grid"):
-                model.packed_rows = mode == "packed"
+            # packed: both phases on packed rows (src_lens handed over on the host, as a caller that collates on the host has them);
+            # packed_phase2_only: src_lens on the device, as synthesize.py's to_device leaves them (phase 1 stays on the grid);
+            # grid: the reference's padded grids throughout
+            for mode in ("packed", "packed_phase2_only", "grid"):
+                model.packed_rows = mode != "grid"
+                lens_arg = rln_host if mode == "packed" else ra[2]
                 with torch.no_grad():
                     for _ in range(3):
-                        ro = model(ra[0], ra[1], ra[2], L)
+                        ro = model(ra[0], ra[1], lens_arg, L)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     for _ in range(10):
-                        ro = model(ra[0], ra[1], ra[2], L)
+                        ro = model(ra[0], ra[1], lens_arg, L)
                     torch.cuda.synchronize()
                     dt = (time.perf_counter() - t0) / 10
                 vf = int(ro[9].sum())
                 vl[mode] = {"ms_per_step": round(dt * 1e3, 3), "value": round(vf / dt, 1), "unit": "frames/s",
-                            "rows_phase2": int(model._lib.ns_last_phase2_rows(model._h))}
+                            "rows_phase2": int(model._lib.ns_last_phase2_rows(model._h)),
+                            "phase1_rows": int(model._lib.ns_last_phase1_rows(model._h))}
                 vl["T_pad"], vl["valid_frames"] = int(ro[0].shape[1]), vf
         finally:
             model.packed_rows = keep
         vl["speedup"] = round(vl["grid"]["ms_per_step"] / vl["packed"]["ms_per_step"], 3)
+        vl["phase1_rows"] = vl["packed"]["phase1_rows"]
+        vl["phase1_rows_grid"] = vl["grid"]["phase1_rows"]
         vl["workload"] = f"{args.workload} with ragged lengths (phoneme counts uniform in [L/8, L], B={B_shard})"
         res["variable_length"] = vl
 

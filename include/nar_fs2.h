@@ -61,6 +61,10 @@ typedef struct ns_config {
                                csrc/attention.hip); 1 = "two_launch": the same row functions as separate launches, no ticket is
                                ever drawn.  Same bits either way — the switch exists so that tests can A/B the ticket protocol
                                (tests/test_gpu_stress.py).  The full-row tile of large launches needs no ticket and is not affected */
+  int32_t phase1_packing;   /* ns_forward_durations_packed: 0 = auto — pack the phoneme rows when >= 10 % of the [B, L] grid is padding AND the
+                               smaller row count saves a whole step of 256 workgroups of the phase's dominant launch (small grids: time
+                               is steps, not rows); 1 = pack whenever >= 10 % is padding (tests exercise the path on small shapes);
+                               2 = never */
 } ns_config;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -109,6 +113,18 @@ int ns_forward_durations(ns_model* m, const int64_t* texts, const int64_t* src_l
                          void* ws_enc, size_t ws_enc_bytes,
                          float* log_d, float* d_rounded, uint8_t* src_mask, int64_t* mel_lens, float* p_pred, float* e_pred,
                          int64_t* mel_lens_host, void* stream);
+/* The same with the HOST copy of src_lens (what a caller that builds its batches on the host has anyway: dataset.py:182-191,
+ * utils/tools.py:254-264): ragged phoneme counts then run phase 1 on PACKED phoneme rows — utterance b keeps
+ * min(src_lens[b] + 2, L) rows instead of L (transformer/Models.py:73-100 computes, then zeroes, every padded phoneme) — when that
+ * saves >= 10 % of the rows and both variance features are frame_level.  Same outputs, padded like the reference's; values agree
+ * with ns_forward_durations to fp32 summation order (another row count picks other tiles on the small-grid ladder).
+ * ns_last_phase1_rows: the row count the most recent phase 1 ran on (B*L, or the packed rows). */
+int ns_forward_durations_packed(ns_model* m, const int64_t* texts, const int64_t* src_lens, const int64_t* src_lens_host, int B, int L,
+                                float d_control, float p_control, float e_control, const float* p_targets, const float* e_targets,
+                                void* ws_enc, size_t ws_enc_bytes,
+                                float* log_d, float* d_rounded, uint8_t* src_mask, int64_t* mel_lens, float* p_pred, float* e_pred,
+                                int64_t* mel_lens_host, void* stream);
+int64_t ns_last_phase1_rows(const ns_model* m);
 
 /* Phase 2: LengthRegulator + frame-level pitch/energy + MelDecoder + mel_linear + PostNet (+ residual).
  * T is max(mel_lens), or a caller-chosen capacity (max_mel_len, model/modules.py:128-131,204-213 semantics: the mel axis is
@@ -208,6 +224,8 @@ int ns_op_attention_core(const float* qkv, const int64_t* lens, int B, int S, in
 #define NS_PROFILE_OFF 0
 #define NS_PROFILE_ALL 1
 #define NS_PROFILE_SLOT(i) (2 << (i)) /* OR several together to time exactly those slots */
+#define NS_PROFILE_KEEP 0x10000        /* OR into `on`: keep the events recorded so far (bench.py times every 5th forward of its
+                                          timed region: NS_PROFILE_KEEP | NS_PROFILE_SLOT(0) on those, NS_PROFILE_KEEP alone between) */
 int ns_profile_enable(ns_model* m, int on);
 int ns_profile_read(ns_model* m, double* total_ms, double* total_flops, int64_t* launches);
 int ns_profile_read_slot(ns_model* m, int slot, double* total_ms, double* total_flops, int64_t* launches);

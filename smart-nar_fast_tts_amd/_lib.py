@@ -21,7 +21,7 @@ class NsConfig(C.Structure):
         "n_vocab", "max_seq_len", "d_enc", "n_enc_layer", "n_enc_head", "d_dec", "n_dec_layer", "n_dec_head",
         "d_inner", "ffn_k1", "ffn_k2", "vp_filter", "vp_kernel", "n_bins", "n_mel",
         "postnet_dim", "postnet_k", "postnet_n", "pitch_frame_level", "energy_frame_level", "length_regulator",
-        "matmul_bf16x3", "row_epilogue")]
+        "matmul_bf16x3", "row_epilogue", "phase1_packing")]
 
 
 _P, _I, _F, _Z, _S = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_char_p
@@ -40,6 +40,8 @@ SIGNATURES = {
     "ns_encoder_ws_bytes": (_Z, [_P, _I, _I]),
     "ns_decoder_ws_bytes": (_Z, [_P, _I, _I, _I]),
     "ns_forward_durations": (_I, [_P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ns_forward_durations_packed": (_I, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ns_last_phase1_rows": (C.c_int64, [_P]),
     "ns_forward_mel": (_I, [_P, _I, _I, _I, _P, _F, _F, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _P]),
     "ns_forward_mel_packed": (_I, [_P, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _P]),
 

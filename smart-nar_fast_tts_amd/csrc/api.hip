@@ -60,6 +60,7 @@ struct ns_model {
   // Measurement state, not model state: mutable so that the (const) forward helpers can record into it.
   struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double flops = 0.0; };
   mutable long long last_rows = 0;  // rows phase 2 of the most recent ns_forward_mel[_packed] ran on (B*T, or the packed windows)
+  mutable long long last_rows1 = 0; // rows phase 1 of the most recent ns_forward_durations[_packed] ran on (B*L, or the packed phoneme rows)
   mutable unsigned prof = 0;  // bit i: slot i is timed (ns_profile_enable)
   mutable bool prof_active = false;
   mutable ProfSlot prof_slot[NS_PROFILE_SLOTS];
@@ -144,6 +145,7 @@ extern "C" int ns_create(const ns_config* cfg, ns_model** out) {
   if (c.length_regulator != 0 && c.length_regulator != 1) return fail("ns_create: length_regulator must be 0 (hard) or 1 (gaussian)");
   if (c.matmul_bf16x3 != 0 && c.matmul_bf16x3 != 1) return fail("ns_create: matmul_bf16x3 must be 0 (fp32) or 1 (bf16x3)");
   if (c.row_epilogue != 0 && c.row_epilogue != 1) return fail("ns_create: row_epilogue must be 0 (fused) or 1 (two_launch)");
+  if (c.phase1_packing < 0 || c.phase1_packing > 2) return fail("ns_create: phase1_packing must be 0 (auto), 1 (always) or 2 (never)");
   if (c.vp_kernel != 3) return fail("ns_create: variance predictor conv1d_2 hard-codes padding=1 (model/modules.py:267); kernel_size must be 3");
   ns_model* m = new ns_model();
   m->cfg = c;
@@ -461,6 +463,7 @@ extern "C" size_t ns_op_ws_bytes(const ns_model* m, int B, int S) {
   carve(m->cfg, bp, (size_t)B * S, S);
   return bp.off + 256;
 }
+static size_t phase1_packed_extra_bytes(const ns_config& c, int B, int L);
 extern "C" size_t ns_encoder_ws_bytes(const ns_model* m, int B, int L) {
   if (!m || B <= 0 || L <= 0) return 256;
   Bump bp(nullptr, 0);
@@ -468,7 +471,7 @@ extern "C" size_t ns_encoder_ws_bytes(const ns_model* m, int B, int L) {
   bp.raw((size_t)B * L * sizeof(int32_t));  // duration prefix sums (kept for phase 2)
   bp.f((size_t)B * L);                       // rounded durations (kept for phase 2: Gaussian length regulator)
   carve(m->cfg, bp, (size_t)B * L, L);
-  return bp.off + 256;
+  return bp.off + phase1_packed_extra_bytes(m->cfg, B, L) + 256;  // (+ ns_forward_durations_packed's plan and packed outputs)
 }
 static size_t packed_extra_bytes(const ns_config& c, int B, int T);
 extern "C" size_t ns_decoder_ws_bytes(const ns_model* m, int B, int L, int T) {
@@ -705,11 +708,13 @@ static int postnet_constants(ns_model* m, hipStream_t st) {
 static int encoder(const ns_model* m, const long long* texts, const long long* lens, int B, int L, float* out, Scratch& sc,
                    hipStream_t st) {
   const ns_config& c = m->cfg;
-  const int M = B * L, d = c.d_enc;
+  const int M = rows_of(B, L), d = c.d_enc;
   const float* pos;
   NS_TRY(position_rows(m, m->enc_pos, L, d, sc, &pos, st));
   float* cur = m->enc.empty() ? out : sc.xa;
-  NS_HIP(launch_embed_pos(texts, m->P(m->emb), pos, cur, M, L, d, c.n_vocab, sc.tickets, TICKET_INTS, st));  // + zeroes the phase's tickets
+  // (+ zeroes the phase's tickets)
+  if (tl_pk) NS_HIP(launch_embed_pos_packed(texts, m->P(m->emb), pos, cur, tl_pk->rm, B, M, L, d, c.n_vocab, sc.tickets, TICKET_INTS, st));
+  else NS_HIP(launch_embed_pos(texts, m->P(m->emb), pos, cur, M, L, d, c.n_vocab, sc.tickets, TICKET_INTS, st));
   for (size_t i = 0; i < m->enc.size(); ++i) {
     float* dst = (i + 1 == m->enc.size()) ? out : (cur == sc.xa ? sc.xb : sc.xa);
     NS_TRY(fft_block(m, m->enc[i], d, c.n_enc_head, cur, lens, B, L, dst, sc, st));
@@ -733,40 +738,119 @@ static int decoder_stack(const ns_model* m, float* x, const long long* lens, int
 }
 
 // ------------------------------------------------------------------------------------------- the forward
-extern "C" int ns_forward_durations(ns_model* m, const int64_t* texts, const int64_t* src_lens, int B, int L, float d_control,
-                                    float p_control, float e_control, const float* p_targets, const float* e_targets,
-                                    void* ws_enc, size_t ws_bytes, float* log_d, float* d_rounded, uint8_t* src_mask,
-                                    int64_t* mel_lens, float* p_pred, float* e_pred, int64_t* mel_lens_host, void* stream) {
+// Phase 1: encoder -> [phoneme-level pitch / energy] -> duration predictor -> rounding, prefix sums, mel_lens.
+// lens_host (nullable): the host copy of src_lens.  With it, and when the utterances' phoneme counts leave >= 10 % of the [B, L]
+// grid as padding, everything up to the duration predictor runs on PACKED phoneme rows (kernels.h PHONEME_GUARD: exact, see
+// there) and the padded [B, L] tensors the caller and phase 2 expect are rebuilt before the duration tail.
+static size_t phase1_packed_rows(const int64_t* lens_host, int B, int L) {
+  size_t mp = 0;
+  for (int b = 0; b < B; ++b) {
+    long long l = (lens_host[b] < 0 ? 0 : lens_host[b]) + PHONEME_GUARD;
+    mp += (size_t)(l < (long long)L ? l : (long long)L);
+  }
+  return mp;
+}
+static size_t phase1_packed_extra_bytes(const ns_config& c, int B, int L) {  // plan + packed encoder output + packed log-durations
+  Bump bp(nullptr, 0);
+  const size_t M = (size_t)B * L;
+  bp.raw(pack_plan_ints(B, M) * sizeof(int));
+  bp.f(M * c.d_enc); bp.f(M);
+  return bp.off;
+}
+
+static int forward_durations(ns_model* m, const int64_t* texts, const int64_t* src_lens, const int64_t* lens_host, int B, int L, float d_control,
+                             float p_control, float e_control, const float* p_targets, const float* e_targets,
+                             void* ws_enc, size_t ws_bytes, float* log_d, float* d_rounded, uint8_t* src_mask,
+                             int64_t* mel_lens, float* p_pred, float* e_pred, int64_t* mel_lens_host, void* stream) {
   NS_TRY(check_ready(m));
   if (B <= 0 || L <= 0) return fail("ns_forward_durations: empty batch");
   if (ws_bytes < ns_encoder_ws_bytes(m, B, L)) return fail("ns_forward_durations: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const ns_config& c = m->cfg;
+  if (!c.pitch_frame_level && !p_pred) return fail("ns_forward_durations: phoneme_level pitch needs a p_pred [B,L] output");
+  if (!c.energy_frame_level && !e_pred) return fail("ns_forward_durations: phoneme_level energy needs an e_pred [B,L] output");
   Bump bp(ws_enc, ws_bytes);
   float* enc_out = bp.f((size_t)B * L * c.d_enc);
   int32_t* cum = (int32_t*)bp.raw((size_t)B * L * sizeof(int32_t));
   float* dur_keep = bp.f((size_t)B * L);
-  Scratch sc = carve(c, bp, (size_t)B * L, L);
   const long long* lens = (const long long*)src_lens;
-  NS_TRY(encoder(m, (const long long*)texts, lens, B, L, enc_out, sc, st));
-  NS_TRY(predictor(m, m->pred[0], enc_out, lens, B, L, 1.0f, nullptr, log_d, nullptr, nullptr, nullptr, nullptr, sc, st));
-  // phoneme_level features are predicted on the encoder output, before the length regulator, pitch first, and
-  // added in place (model/modules.py:117-126); the duration predictor above saw x before these adds (:116)
-  if (!c.pitch_frame_level) {
-    if (!p_pred) return fail("ns_forward_durations: phoneme_level pitch needs a p_pred [B,L] output");
-    NS_TRY(predictor(m, m->pred[1], enc_out, lens, B, L, p_control, p_targets, p_pred, m->P(m->pitch_bins), m->P(m->pitch_emb),
-                     nullptr, enc_out, sc, st));
+  size_t Mp = 0;
+  // (phoneme-level pitch / energy add an embedding row to PADDED phonemes too — model/modules.py:117-126, an unmasked add whose
+  //  index comes from the caller's target at that very position — so those configurations keep the grid; the shipped one is frame_level)
+  bool packed = lens_host && !m->enc.empty() && launch_planner_enabled() && c.pitch_frame_level && c.energy_frame_level && c.phase1_packing != 2;
+  if (packed) {
+    // Phase-1 launches are small grids: their time is steps of 256 workgroups x a K loop, not rows (measured, config-2 shape with
+    // 0.66 of the rows: 4.27 ms packed vs 4.22 ms on the grid — the same two steps everywhere, plus the plan / unpack / attention-merge
+    // launches).  So pack only when the rows drop by a whole step of the launch that dominates the phase, the FFN k=9 GEMM on
+    // 32x128 tiles (4 x ~38 us per step saved against ~50 us of extra launches), and by at least 10 %.
+    Mp = phase1_packed_rows(lens_host, B, L);
+    auto steps = [&](size_t rows) { return ((rows + 31) / 32 * ((size_t)c.d_inner / 128) + 255) / 256; };
+    packed = Mp > 0 && Mp * 10 <= (size_t)B * L * 9 && (c.phase1_packing == 1 || steps(Mp) < steps((size_t)B * L));
   }
-  if (!c.energy_frame_level) {
-    if (!e_pred) return fail("ns_forward_durations: phoneme_level energy needs an e_pred [B,L] output");
-    NS_TRY(predictor(m, m->pred[2], enc_out, lens, B, L, e_control, e_targets, e_pred, m->P(m->energy_bins), m->P(m->energy_emb),
-                     nullptr, enc_out, sc, st));
+  const size_t Mrows = packed ? Mp : (size_t)B * L;
+  m->last_rows1 = (long long)Mrows;
+  Scratch sc = carve(c, bp, Mrows, L, packed);
+  PackedCtx pk;
+  memset(&pk, 0, sizeof(pk));
+  float *enc_w = enc_out, *logd_w = log_d;
+  if (packed) {
+    const int M = (int)Mp, d = c.d_enc;
+    int base = 0;  // the attention work list's length, from the same lengths the device plan reads
+    for (int b = 0; b < B; ++b) {
+      long long l = (lens_host[b] < 0 ? 0 : lens_host[b]) + PHONEME_GUARD;
+      base += (int)(((l < L ? l : L) + 127) / 128) * c.n_enc_head;
+    }
+    size_t n = (size_t)attention_split_packed(base, L, d / c.n_enc_head, Mp, d);
+    const size_t per = Mp * d + 2 * Mp * c.n_enc_head;
+    const size_t extra = phase1_packed_extra_bytes(c, B, L);
+    const size_t avail = ws_bytes > bp.off + extra ? (ws_bytes - bp.off - extra) / sizeof(float) : 0;
+    while (n > 1 && n * per > avail) --n;
+    if (n > 1) { sc.att_part_floats = n * per; sc.att_part = bp.f(sc.att_part_floats); }
+    int* plan = (int*)bp.raw(pack_plan_ints(B, Mp) * sizeof(int));
+    enc_w = bp.f(Mp * d); logd_w = bp.f(Mp);
+    if (bp.off > ws_bytes) return fail("ns_forward_durations: workspace too small (packed rows)");
+    pk.Mp = M;
+    pk.rm.rows = M;
+    pk.rm.att_wgs = base;
+    NS_HIP(launch_pack_plan_only(lens, B, L, c.n_enc_head, M, plan, &pk.rm, st, PHONEME_GUARD));  // (row maps: the embedding kernel)
+  }
+  {
+    PackedScope scope(packed ? &pk : nullptr);
+    NS_TRY(encoder(m, (const long long*)texts, lens, B, L, enc_w, sc, st));
+    NS_TRY(predictor(m, m->pred[0], enc_w, lens, B, L, 1.0f, nullptr, logd_w, nullptr, nullptr, nullptr, nullptr, sc, st));
+    // phoneme_level features are predicted on the encoder output, before the length regulator, pitch first, and
+    // added in place (model/modules.py:117-126); the duration predictor above saw x before these adds (:116)
+    if (!c.pitch_frame_level)
+      NS_TRY(predictor(m, m->pred[1], enc_w, lens, B, L, p_control, p_targets, p_pred, m->P(m->pitch_bins), m->P(m->pitch_emb), nullptr, enc_w, sc, st));
+    if (!c.energy_frame_level)
+      NS_TRY(predictor(m, m->pred[2], enc_w, lens, B, L, e_control, e_targets, e_pred, m->P(m->energy_bins), m->P(m->energy_emb), nullptr, enc_w, sc, st));
+  }
+  if (packed) {  // the padded tensors phase 2 and the caller read
+    // (masked rows are zeros already; rows past a window become zeros; log_d is 0 at every padded phoneme)
+    NS_HIP(launch_unpack_phase1(pk.rm, lens, B, L, c.d_enc, enc_w, enc_out, logd_w, log_d, st));
   }
   // src mask (utils/tools.py:89-97), duration rounding (model/modules.py:132-135), repeat counts + prefix sums + mel_len
   // (:209-223): one launch
   NS_HIP(launch_duration_tail(log_d, lens, (const long long*)texts, c.n_vocab, B, L, d_control, d_rounded, dur_keep, cum,
                               (long long*)mel_lens, src_mask, (long long*)mel_lens_host, st));
   return 0;
+}
+
+extern "C" int ns_forward_durations(ns_model* m, const int64_t* texts, const int64_t* src_lens, int B, int L, float d_control,
+                                    float p_control, float e_control, const float* p_targets, const float* e_targets,
+                                    void* ws_enc, size_t ws_bytes, float* log_d, float* d_rounded, uint8_t* src_mask,
+                                    int64_t* mel_lens, float* p_pred, float* e_pred, int64_t* mel_lens_host, void* stream) {
+  return forward_durations(m, texts, src_lens, nullptr, B, L, d_control, p_control, e_control, p_targets, e_targets, ws_enc, ws_bytes, log_d,
+                           d_rounded, src_mask, mel_lens, p_pred, e_pred, mel_lens_host, stream);
+}
+
+extern "C" int ns_forward_durations_packed(ns_model* m, const int64_t* texts, const int64_t* src_lens, const int64_t* src_lens_host, int B, int L,
+                                           float d_control, float p_control, float e_control, const float* p_targets, const float* e_targets,
+                                           void* ws_enc, size_t ws_bytes, float* log_d, float* d_rounded, uint8_t* src_mask,
+                                           int64_t* mel_lens, float* p_pred, float* e_pred, int64_t* mel_lens_host, void* stream) {
+  if (!src_lens_host) return fail("ns_forward_durations_packed: src_lens_host (the host copy of src_lens) is required");
+  return forward_durations(m, texts, src_lens, src_lens_host, B, L, d_control, p_control, e_control, p_targets, e_targets, ws_enc, ws_bytes, log_d,
+                           d_rounded, src_mask, mel_lens, p_pred, e_pred, mel_lens_host, stream);
 }
 
 // Packed phase 2 (kernels.h RowMap).  The reference runs everything behind the length regulator on the dense [B, T] grid and
@@ -932,6 +1016,7 @@ static int forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens
 }
 
 extern "C" int64_t ns_last_phase2_rows(const ns_model* m) { return m ? (int64_t)m->last_rows : 0; }
+extern "C" int64_t ns_last_phase1_rows(const ns_model* m) { return m ? (int64_t)m->last_rows1 : 0; }
 
 extern "C" int ns_forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens, float p_control, float e_control,
                               const float* p_targets, const float* e_targets,
@@ -1046,8 +1131,11 @@ extern "C" int ns_op_variance_embedding(ns_model* m, int which, const float* x, 
 }
 extern "C" int ns_profile_enable(ns_model* m, int on) {
   if (!m) return fail("ns_profile_enable: null model");
+  const bool keep = on > 0 && (on & NS_PROFILE_KEEP) != 0;  // change the set of timed slots, keep what was recorded so far
+  if (on > 0) on &= ~NS_PROFILE_KEEP;
   m->prof = on == 1 ? (1u << NS_PROFILE_SLOTS) - 1u : on < 0 ? 0u : ((unsigned)on >> 1);  // 1 = every slot; 2 * mask = those slots
-  for (auto& ps : m->prof_slot) { ps.used = 0; ps.flops = 0.0; }
+  if (!keep)
+    for (auto& ps : m->prof_slot) { ps.used = 0; ps.flops = 0.0; }
   return 0;
 }
 extern "C" int ns_profile_read_slot(ns_model* m, int slot, double* total_ms, double* total_flops, int64_t* launches) {

@@ -145,7 +145,20 @@ hipError_t launch_length_regulate_packed(const float* x, const int32_t* cum, int
 hipError_t launch_broadcast_row(const float* row, float* dst, int rows, int n, hipStream_t st);
 hipError_t launch_pack_vector(const RowMap& rm, int T, const float* src, float* dst, int Mp, hipStream_t st);
 // the packing plan and row maps alone (launch_length_regulate_packed builds them as a side effect of its gather)
-hipError_t launch_pack_plan(const long long* mel_lens, int B, int T, int H, int Mp, int* plan, RowMap* rm, hipStream_t st);
+hipError_t launch_pack_plan(const long long* mel_lens, int B, int T, int H, int Mp, int* plan, RowMap* rm, hipStream_t st, int guard = PACK_GUARD);
+// Phase 1 on packed PHONEME rows (api.hip forward_durations): utterance b keeps min(src_len[b] + PHONEME_GUARD, L) rows.  In the
+// FFT blocks a valid phoneme never reads a padded one except as zeros (masked_fill ahead of every convolution, -inf keys); the
+// variance predictors have no mask between their two convolutions (model/modules.py:245-286), so the last valid
+// phoneme reads ONE row past the utterance's end — a row that must be computed, from zeroed encoder output, like the reference does.
+constexpr int PHONEME_GUARD = 2;
+hipError_t launch_pack_plan_only(const long long* lens, int B, int T, int H, int Mp, int* plan, RowMap* rm, hipStream_t st, int guard);
+// (also writes the row maps of *rm: launch_pack_plan_only + this kernel = the whole plan)
+hipError_t launch_embed_pos_packed(const long long* texts, const float* emb, const float* pos, float* out, const RowMap& rm, int B, int Mp, int L,
+                                   int D, int n_vocab, int* zero, int nzero, hipStream_t st);
+hipError_t launch_unpack_phase1(const RowMap& rm, const long long* lens, int B, int S, int D, const float* rows_p, float* rows, const float* vec_p,
+                                float* vec, hipStream_t st);
+// dst [B*S, D] (any D) = the packed rows of src where t < min(lens[b], win[b]), zeros elsewhere
+hipError_t launch_unpack_rows(const RowMap& rm, const long long* lens, int B, int S, int D, const float* src, float* dst, hipStream_t st);
 // padded outputs from packed rows (api.hip forward_mel): see k_unpack_outputs in rowops.hip
 hipError_t launch_unpack_outputs(const RowMap& rm, int B, int T, int n_mel, const long long* mel_lens, const float* mel_p, const float* post_p,
                                  const float* p_p, const float* e_p, const float* mel_bias, const float* post_const, float* mel,

@@ -146,6 +146,87 @@ hipError_t launch_embed_pos(const long long* texts, const float* emb, const floa
   return hipGetLastError();
 }
 
+static void plan_pointers(int* plan, int B, int Mp, RowMap* rm);
+// The same on packed phoneme rows (kernels.h RowMap, api.hip forward_durations): row m is phoneme row_t[m] of utterance row_b[m].
+// Also zeroes the phase's ticket counters (the plan kernels ahead of it do not).
+__global__ __launch_bounds__(256) void k_embed_pos_packed(const long long* __restrict__ texts, const float* __restrict__ emb,
+                                                           const float* __restrict__ pos, float* __restrict__ out, int Mp, int L, int D,
+                                                           int n_vocab, int B, const int* __restrict__ off, const int* __restrict__ win,
+                                                           int* __restrict__ row_b, int* __restrict__ row_t, int* __restrict__ row_w,
+                                                           int* __restrict__ zero, int nzero) {
+  zero_words(zero, nzero);
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= Mp) return;
+  int lo = 0, hi = B - 1;  // largest b with off[b] <= m; this kernel also writes the row maps every later kernel reads
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (off[mid] <= m) lo = mid;
+    else hi = mid - 1;
+  }
+  const int t = m - off[lo];
+  if (lane == 0) { row_b[m] = lo; row_t[m] = t; row_w[m] = win[lo]; }
+  long long tok = texts[(size_t)lo * L + t];
+  if (tok < 0 || tok >= (long long)n_vocab) tok = 0;
+  for (int c = lane * 4; c < D; c += 256) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(emb + (size_t)tok * D + c);
+    a += *reinterpret_cast<const f32x4*>(pos + (size_t)t * D + c);
+    *reinterpret_cast<f32x4*>(out + (size_t)m * D + c) = a;
+  }
+}
+hipError_t launch_embed_pos_packed(const long long* texts, const float* emb, const float* pos, float* out, const RowMap& rm, int B, int Mp, int L,
+                                   int D, int n_vocab, int* zero, int nzero, hipStream_t st) {
+  if (Mp <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_embed_pos_packed, dim3((Mp + 3) / 4), dim3(256), 0, st, texts, emb, pos, out, Mp, L, D, n_vocab, B, rm.off, rm.win,
+                     const_cast<int*>(rm.row_b), const_cast<int*>(rm.row_t), const_cast<int*>(rm.row_w), zero, nzero);
+  return hipGetLastError();
+}
+
+// dense [B*S, D] rows from packed rows: row (b, t) = the packed row off[b] + t when t < min(lens[b], win[b]), zeros otherwise
+// (what the reference's masked_fill leaves on a padded phoneme: transformer/Layers.py:43,46, model/modules.py:283-284)
+__global__ __launch_bounds__(256) void k_unpack_rows(const int* __restrict__ off, const int* __restrict__ win, const long long* __restrict__ lens,
+                                                      int B, int S, int D, const float* __restrict__ src, float* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= B * S) return;
+  const int b = m / S, t = m - b * S;
+  long long len = lens ? lens[b] : (long long)S;
+  const bool live = t < win[b] && (long long)t < len;
+  const float* s = src + ((size_t)off[b] + t) * D;
+  float* d = dst + (size_t)m * D;
+  if ((D & 3) == 0) {
+    for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<f32x4*>(d + c) = live ? *reinterpret_cast<const f32x4*>(s + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  } else {
+    for (int c = lane; c < D; c += 64) d[c] = live ? s[c] : 0.f;
+  }
+}
+hipError_t launch_unpack_rows(const RowMap& rm, const long long* lens, int B, int S, int D, const float* src, float* dst, hipStream_t st) {
+  if (B <= 0 || S <= 0 || D <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_unpack_rows, dim3((B * S + 3) / 4), dim3(256), 0, st, rm.off, rm.win, lens, B, S, D, src, dst);
+  return hipGetLastError();
+}
+
+// phase 1's two padded tensors in one launch: rows [B*S, D] (zeros past a window) and a vector [B*S] (zeros at t >= lens[b])
+__global__ __launch_bounds__(256) void k_unpack_phase1(const int* __restrict__ off, const int* __restrict__ win, const long long* __restrict__ lens,
+                                                        int B, int S, int D, const float* __restrict__ rows_p, float* __restrict__ rows,
+                                                        const float* __restrict__ vec_p, float* __restrict__ vec) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= B * S) return;
+  const int b = m / S, t = m - b * S;
+  const bool in_win = t < win[b];
+  const size_t src = (size_t)off[b] + t;
+  if (lane == 0) vec[m] = (in_win && (long long)t < lens[b]) ? vec_p[src] : 0.f;
+  for (int c = lane * 4; c < D; c += 256)
+    *reinterpret_cast<f32x4*>(rows + (size_t)m * D + c) = in_win ? *reinterpret_cast<const f32x4*>(rows_p + src * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+hipError_t launch_unpack_phase1(const RowMap& rm, const long long* lens, int B, int S, int D, const float* rows_p, float* rows, const float* vec_p,
+                                float* vec, hipStream_t st) {
+  if (B <= 0 || S <= 0 || D <= 0 || (D & 3)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_unpack_phase1, dim3((B * S + 3) / 4), dim3(256), 0, st, rm.off, rm.win, lens, B, S, D, rows_p, rows, vec_p, vec);
+  return hipGetLastError();
+}
+
 // MelDecoder.forward input: enc_seq + position table (transformer/Models.py:218-235).
 __global__ __launch_bounds__(256) void k_add_pos(const float* __restrict__ x, const float* __restrict__ pos,
                                                   float* __restrict__ out, int M, int S, int D, const int* __restrict__ row_t) {
@@ -351,11 +432,11 @@ hipError_t launch_length_regulate(const float* x, const int32_t* cum, int B, int
 // attention work list: utterances ranked by descending window (ties by index), att_off = exclusive scan of
 // ceil(win / 128) * H in rank order.
 __global__ __launch_bounds__(256) void k_pack_plan(const long long* __restrict__ mel_lens, int B, int T, int H, int* __restrict__ off,
-                                                    int* __restrict__ win, int* __restrict__ att_off, int* __restrict__ att_order) {
+                                                    int* __restrict__ win, int* __restrict__ att_off, int* __restrict__ att_order, int guard) {
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     long long l = mel_lens[b];
     if (l < 0) l = 0;
-    l += PACK_GUARD;
+    l += guard;
     win[b] = (int)(l < (long long)T ? l : (long long)T);
   }
   __syncthreads();
@@ -403,11 +484,20 @@ static void plan_pointers(int* plan, int B, int Mp, RowMap* rm) {
   rm->row_b = row_b; rm->row_t = row_b + Mp; rm->row_w = row_b + 2 * (size_t)Mp;
 }
 
-hipError_t launch_pack_plan(const long long* mel_lens, int B, int T, int H, int Mp, int* plan, RowMap* rm, hipStream_t st) {
+// the plan alone (offsets, windows, attention work list); the row maps are written by the kernel that opens the phase
+hipError_t launch_pack_plan_only(const long long* lens, int B, int T, int H, int Mp, int* plan, RowMap* rm, hipStream_t st, int guard) {
+  if (B <= 0 || Mp <= 0 || !plan || !rm || !lens) return hipErrorInvalidValue;
+  plan_pointers(plan, B, Mp, rm);
+  hipLaunchKernelGGL(k_pack_plan, dim3(1), dim3(256), 0, st, lens, B, T, H, const_cast<int*>(rm->off), const_cast<int*>(rm->win),
+                     const_cast<int*>(rm->att_off), const_cast<int*>(rm->att_order), guard);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_plan(const long long* mel_lens, int B, int T, int H, int Mp, int* plan, RowMap* rm, hipStream_t st, int guard) {
   if (B <= 0 || Mp <= 0 || !plan || !rm || !mel_lens) return hipErrorInvalidValue;
   plan_pointers(plan, B, Mp, rm);
   hipLaunchKernelGGL(k_pack_plan, dim3(1), dim3(256), 0, st, mel_lens, B, T, H, const_cast<int*>(rm->off), const_cast<int*>(rm->win),
-                     const_cast<int*>(rm->att_off), const_cast<int*>(rm->att_order));
+                     const_cast<int*>(rm->att_off), const_cast<int*>(rm->att_order), guard);
   hipLaunchKernelGGL(k_pack_rows, dim3((Mp + 255) / 256), dim3(256), 0, st, rm->off, rm->win, B, Mp, const_cast<int*>(rm->row_b),
                      const_cast<int*>(rm->row_t), const_cast<int*>(rm->row_w));
   return hipGetLastError();
@@ -459,7 +549,7 @@ hipError_t launch_length_regulate_packed(const float* x, const int32_t* cum, int
   int* off = const_cast<int*>(rm->off);
   int* win = const_cast<int*>(rm->win);
   hipLaunchKernelGGL(k_pack_plan, dim3(1), dim3(256), 0, st, mel_lens, B, T, H, off, win, const_cast<int*>(rm->att_off),
-                     const_cast<int*>(rm->att_order));  // (att_wgs, rows: the caller's, from its host copy of the lengths)
+                     const_cast<int*>(rm->att_order), PACK_GUARD);  // (att_wgs, rows: the caller's, from its host copy of the lengths)
   hipLaunchKernelGGL(k_length_regulate_packed, dim3((Mp + 3) / 4), dim3(256), 0, st, x, cum, B, L, D, T, Mp, out, mel_lens, status, off, win,
                      const_cast<int*>(rm->row_b), const_cast<int*>(rm->row_t), const_cast<int*>(rm->row_w), zero, nzero);
   return hipGetLastError();

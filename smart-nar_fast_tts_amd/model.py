@@ -53,6 +53,8 @@ def config_struct(preprocess_config: dict, model_config: dict) -> _lib.NsConfig:
         # EXTENSION key (tests): "two_launch" never draws a ticket — LayerNorm / predictor tails / attention merges of small
         # grids run as separate launches instead of last-arriver epilogues (include/nar_fs2.h ns_config.row_epilogue); same bits
         row_epilogue={"fused": 0, "two_launch": 1}[model_config.get("row_epilogue", "fused")],
+        # EXTENSION key: when phase 1 packs ragged phoneme rows (host src_lens; include/nar_fs2.h ns_config.phase1_packing)
+        phase1_packing={"auto": 0, "always": 1, "never": 2}[model_config.get("phase1_packing", "auto")],
     )
 
 
@@ -391,9 +393,10 @@ class FastSpeech2Align:
         four of them per forward, not eleven."""
         self.profile_slots((0,) if on else ())
 
-    def profile_slots(self, slots=(0, 1, 2)):
-        """Time exactly these launch groups (include/nar_fs2.h NS_PROFILE_SLOT); () switches the hook off."""
-        mask = 0
+    def profile_slots(self, slots=(0, 1, 2), keep: bool = False):
+        """Time exactly these launch groups (include/nar_fs2.h NS_PROFILE_SLOT); () switches the hook off.  ``keep``: do not
+        discard what was recorded so far (sampling: time every n-th forward of a region, read once at its end)."""
+        mask = 0x10000 if keep else 0
         for i in slots:
             mask |= 2 << int(i)
         _lib.check(self._lib.ns_profile_enable(self._h, mask), "ns_profile_enable")
@@ -516,7 +519,17 @@ class FastSpeech2Align:
         if int(max_src_len) != L:
             raise ValueError(f"max_src_len ({int(max_src_len)}) must equal texts.shape[1] ({L})")
         texts_c = texts.long().contiguous()
-        lens_c = src_lens.to(device=dev, dtype=torch.long).contiguous()
+        # src_lens on the HOST (a CPU tensor, numpy array or list: what a caller that collates on the host holds, dataset.py:182-191)
+        # lets phase 1 run on packed phoneme rows for ragged batches; a device tensor is used as it is (reading it would be a sync)
+        lens_host = None
+        if not (torch.is_tensor(src_lens) and src_lens.is_cuda):
+            lens_host = np.ascontiguousarray(src_lens.numpy() if torch.is_tensor(src_lens) else np.asarray(src_lens), dtype=np.int64)
+            if lens_host.shape != (B,):
+                raise ValueError(f"src_lens must have shape ({B},), got {lens_host.shape}")
+            src_lens_t = torch.from_numpy(lens_host)
+        else:
+            src_lens_t = src_lens
+        lens_c = src_lens_t.to(device=dev, dtype=torch.long).contiguous()
         # a phoneme_level feature is predicted on the encoder output ([B,L], model/modules.py:117-126),
         # a frame_level one after the length regulator ([B,T], :139-149)
         p_frame, e_frame = bool(self._cfg.pitch_frame_level), bool(self._cfg.energy_frame_level)
@@ -556,12 +569,16 @@ class FastSpeech2Align:
             blk1 = _OutputBlock(o1, dev)
             ws_enc = self._workspace("enc", self._ws_bytes("enc", B, L, 0), sh)
             pin, pin_np = self._pinned_lens(B, sh)
-            _lib.check(lib.ns_forward_durations(
-                self._h, _lib.ptr(texts_c), _lib.ptr(lens_c), B, L, 1.0, float(p_control), float(e_control),
-                _lib.ptr(None if p_frame else target("p_targets", p_targets, (B, L))),
-                _lib.ptr(None if e_frame else target("e_targets", e_targets, (B, L))),
-                _lib.ptr(ws_enc), ws_enc.numel(), blk1.ptr("log_d"), blk1.ptr("d_rounded"), blk1.ptr("src_masks"),
-                blk1.ptr("mel_lens"), blk1.ptr("p_pred"), blk1.ptr("e_pred"), _lib.ptr(pin), st), "ns_forward_durations")
+            tail1 = (B, L, 1.0, float(p_control), float(e_control),
+                     _lib.ptr(None if p_frame else target("p_targets", p_targets, (B, L))),
+                     _lib.ptr(None if e_frame else target("e_targets", e_targets, (B, L))),
+                     _lib.ptr(ws_enc), ws_enc.numel(), blk1.ptr("log_d"), blk1.ptr("d_rounded"), blk1.ptr("src_masks"),
+                     blk1.ptr("mel_lens"), blk1.ptr("p_pred"), blk1.ptr("e_pred"), _lib.ptr(pin), st)
+            if lens_host is not None and self.packed_rows:
+                _lib.check(lib.ns_forward_durations_packed(self._h, _lib.ptr(texts_c), _lib.ptr(lens_c), C.c_void_p(lens_host.ctypes.data), *tail1),
+                           "ns_forward_durations_packed")
+            else:
+                _lib.check(lib.ns_forward_durations(self._h, _lib.ptr(texts_c), _lib.ptr(lens_c), *tail1), "ns_forward_durations")
             blk2 = ws_dec = None
             lens_on_host = False
             fixed_T = isinstance(max_mel_len, (int, np.integer)) and not isinstance(max_mel_len, bool)

@@ -936,3 +936,104 @@ def test_bf16x3_mode_vs_oracle_and_fp32_path():
     sp, tx, ln, L = wl.synth_inputs(2, 20, seed=1)
     with torch.no_grad():
         assert torch.equal(m32(dev(sp), dev(tx), dev(ln), L)[1], mb3(dev(sp), dev(tx), dev(ln), L)[1])
+
+
+def test_phase1_on_packed_phoneme_rows():
+    """include/nar_fs2.h ns_forward_durations_packed: with src_lens on the HOST (a CPU tensor: what a caller that collates on the
+    host holds, dataset.py:182-191) ragged batches run the encoder and the duration predictor on packed phoneme rows —
+    min(src_len + 2, L) rows per utterance instead of the L the reference computes and then zeroes
+    (transformer/Models.py:73-100, transformer/Layers.py:43,46).  Checked: (1) the reference's own fixture with phoneme-side
+    padding, bit for bit on durations and frame counts; (2) ragged batches against the grid run of the same
+    build: integers and masks exact, log-durations / mel within fp32 summation noise, the row count really smaller;
+    (3) no packing where it is not exact or does not pay (phoneme_level features, uniform lengths, device src_lens)."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    # (1) F3(a): the reference's padded-source fixture ("always": the automatic rule only packs when a step of 256 workgroups is saved)
+    meta, z = load_golden("e2e_tiny_padded_src")
+    cfg, sd = weights_for(meta)
+    m = FastSpeech2Align(wl.preprocess_config(), dict(cfg, phase1_packing="always")).to("cuda").eval()
+    m.load_state_dict(sd)
+    L = int(meta["L"])
+    lens = z["in_src_lens"]
+    with torch.no_grad():
+        out = m(dev(z["speakers"]), dev(z["texts"]), torch.from_numpy(np.ascontiguousarray(lens)), L)
+    rows1 = int(m._lib.ns_last_phase1_rows(m._h))
+    expect_rows = int(np.minimum(lens + 2, L).sum())
+    assert (rows1 == expect_rows) == (expect_rows * 10 <= len(lens) * L * 9), (rows1, expect_rows, len(lens) * L)
+    assert np.array_equal(out[5].cpu().numpy(), z["d_rounded"]) and np.array_equal(out[9].cpu().numpy(), z["mel_lens"])
+    assert np.array_equal(out[6].cpu().numpy(), z["src_masks"])
+    close(out[4], z["log_d_predictions"], 2e-5, "log_d on packed phoneme rows vs the reference")
+    assert out[8] is not None and np.array_equal(np.asarray(out[8]), lens)  # src_lens is passed through as it came
+
+    # (2) ragged batches, packed phase 1 (host lens) against the grid (device lens) of the same model
+    for cfg_name, fpp, lens, L, extra in (("ljspeech", 8.0, np.array([128, 10, 64, 1, 100, 33, 127, 17, 128, 5, 77, 2, 60, 90, 31, 111]), 128, {}),
+                                          ("ljspeech", 3.0, np.array([60, 5, 20, 2, 40]), 60, {}),
+                                          ("d512", 8.0, np.array([100, 30, 128, 64, 12, 90]), 128, {}),
+                                          ("ljspeech", 8.0, np.array([100, 7, 64, 1, 33]), 100, {"length_regulator": "gaussian"})):
+        _MODEL.clear()
+        cfg, sd = weights_for(dict(config=cfg_name, weight_seed=0, frames_per_phoneme=fpp, dur_weight_scale=0.25))
+        m = FastSpeech2Align(wl.preprocess_config(), dict(cfg, phase1_packing="always", **extra)).to("cuda").eval()
+        m.load_state_dict(sd)
+        inp = wl.synth_inputs(len(lens), L, seed=9, src_lens=lens)
+        host_lens = torch.from_numpy(np.ascontiguousarray(inp[2]))
+        with torch.no_grad():
+            grid = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3])
+            rows_grid = int(m._lib.ns_last_phase1_rows(m._h))
+            pin = dict(p_targets=grid[2].clone(), e_targets=grid[3].clone())
+            grid_p = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3], **pin)
+            pk = m(dev(inp[0]), dev(inp[1]), host_lens, inp[3], **pin)
+            rows_pk = int(m._lib.ns_last_phase1_rows(m._h))
+            pk_list = m(dev(inp[0]), dev(inp[1]), [int(v) for v in inp[2]], inp[3], **pin)  # a plain list works too
+        assert rows_grid == len(lens) * L and rows_pk == int(np.minimum(lens + 2, L).sum()) and rows_pk < 0.9 * rows_grid, (cfg_name, rows_grid, rows_pk)
+        for i in (5, 6, 7, 9):
+            assert torch.equal(pk[i], grid_p[i]) and torch.equal(pk_list[i], grid_p[i]), (cfg_name, NAMES[i])
+        close(pk[4], grid_p[4].cpu().numpy(), 2e-5, f"{cfg_name}: log_d, packed phoneme rows vs grid")
+        close(pk[0], grid_p[0].cpu().numpy(), 5e-5, f"{cfg_name}: mel, packed phoneme rows vs grid")
+        close(pk[1], grid_p[1].cpu().numpy(), 5e-5, f"{cfg_name}: postnet mel, packed phoneme rows vs grid")
+        # padded phonemes: log_d exactly 0 (masked_fill), like the grid
+        pad = grid_p[6].cpu().numpy()
+        assert np.all(pk[4].cpu().numpy()[pad] == 0.0)
+
+    # (3) where it must not pack
+    _MODEL.clear()
+    cfg, sd = weights_for(dict(config="tiny", weight_seed=0, frames_per_phoneme=4.0, dur_weight_scale=0.25))
+    lens = np.array([20, 4, 11])
+    inp = wl.synth_inputs(3, 20, seed=2, src_lens=lens)
+    host_lens = torch.from_numpy(np.ascontiguousarray(inp[2]))
+    m = FastSpeech2Align(wl.preprocess_config("phoneme_level", "frame_level"), dict(cfg, phase1_packing="always")).to("cuda").eval()
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        a = m(dev(inp[0]), dev(inp[1]), host_lens, inp[3])
+        assert int(m._lib.ns_last_phase1_rows(m._h)) == 60  # phoneme_level pitch adds its embedding to padded phonemes too: grid
+        b = m(dev(inp[0]), dev(inp[1]), dev(inp[2]), inp[3])
+    assert all(torch.equal(a[i], b[i]) for i in (0, 1, 2, 3, 4, 5, 9))
+    m = FastSpeech2Align(wl.preprocess_config(), dict(cfg, phase1_packing="always")).to("cuda").eval()
+    m.load_state_dict(sd)
+    uni = wl.synth_inputs(3, 20, seed=2)
+    with torch.no_grad():
+        m(dev(uni[0]), dev(uni[1]), torch.from_numpy(np.ascontiguousarray(uni[2])), uni[3])
+    assert int(m._lib.ns_last_phase1_rows(m._h)) == 60      # uniform lengths: nothing to save
+    # the automatic rule: small grids cost steps of 256 workgroups, not rows — the same ragged batch is NOT packed when no step
+    # is saved (3 x 20 phonemes), and IS when one is (32 x 128 phonemes at ~0.55 of the rows: 4 steps of the k=9 GEMM -> 3)
+    m = FastSpeech2Align(wl.preprocess_config(), cfg).to("cuda").eval()
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        m(dev(inp[0]), dev(inp[1]), host_lens, inp[3])
+    assert int(m._lib.ns_last_phase1_rows(m._h)) == 60
+    _MODEL.clear()
+    cfg, sd = weights_for(dict(config="ljspeech", weight_seed=0, frames_per_phoneme=2.0, dur_weight_scale=0.25))
+    m = FastSpeech2Align(wl.preprocess_config(), cfg).to("cuda").eval()
+    m.load_state_dict(sd)
+    rr = np.random.RandomState(3)
+    lens = rr.randint(8, 129, size=32)
+    lens[0] = 128
+    big = wl.synth_inputs(32, 128, seed=4, src_lens=lens)
+    with torch.no_grad():
+        o_pk = m(dev(big[0]), dev(big[1]), torch.from_numpy(np.ascontiguousarray(big[2])), big[3])
+        rows_auto = int(m._lib.ns_last_phase1_rows(m._h))
+        o_gr = m(dev(big[0]), dev(big[1]), dev(big[2]), big[3])
+    expect = int(np.minimum(lens + 2, 128).sum())
+    steps = lambda r: -(-((r + 31) // 32) * 8 // 256)  # noqa: E731
+    assert (rows_auto == expect) == (expect * 10 <= 32 * 128 * 9 and steps(expect) < steps(32 * 128)), (rows_auto, expect)
+    assert torch.equal(o_pk[5], o_gr[5]) and torch.equal(o_pk[9], o_gr[9])
