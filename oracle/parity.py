@@ -19,11 +19,14 @@ import numpy as np
 # buckets.  It is set from a RECORDED distribution, not from one observed maximum: tools/bucket_edge_deviation.py measures the
 # deviation of the HIP path on every in-range frame of the five BASELINE pins (profiles/r03_bucket_edge_deviation.md: 48 000
 # frames each for pitch and energy; median 7e-7 / 1.1e-6, p99.9 1.4e-5 / 1.9e-5, worst 2.28e-5 / 2.12e-5) and the bound is
-# 2x the worst value, rounded.  Round 2's 2e-5 sat BELOW the implementation's own worst case (its flips all happened to lie
-# closer to an edge than that).  The tests assert the deviation itself on every in-range frame (max_rel_deviation below), not
+# 2x the worst value, rounded — round 3.  Round 4 re-measured the distribution on the final build (profiles/r04_bucket_edge_deviation.md:
+# worst 2.31e-5 / 2.00e-5 after the row arithmetic's multiply-adds were spelled out) and PINNED the bound closer to it, at 3e-5:
+# the deviation itself is asserted on every in-range frame, so what the bound still has to absorb is the 30 % between the worst
+# frame of 48 000 and the next build's, not a factor of two.  Round 2's 2e-5 sat BELOW the implementation's own worst case (its
+# flips all happened to lie closer to an edge than that).  The tests assert the deviation itself on every in-range frame (max_rel_deviation below), not
 # only the position of the frames that flipped.  Evaluating the predictors' LayerNorm + Linear tail in float64 does not
 # move these figures (2.27e-5 / 2.11e-5): the deviation is the fp32 summation order of the contractions upstream.
-EDGE_REL = 5e-5
+EDGE_REL = 3e-5
 
 
 def in_range(ref: np.ndarray, bins: np.ndarray, valid: np.ndarray) -> np.ndarray:

@@ -9,7 +9,7 @@
 # MI355X_MICROARCH.md prescribes).  bench.py runs with --no-extras under the profiler: the trace then holds exactly
 # (warmup + steps) forwards of the workload, nothing else.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
@@ -33,6 +33,13 @@ for WL in cfg2_b16 cfg5_longform; do
     grep '^{' "$OUT/$TAG.log" | tail -1 > "$OUT/${TAG/_trace/_bench_under_trace}.json"
   done
 done
+# the launch planner's acceptance sweep: forward time against the batch size, this build and (NS_PLAN=0) round 3's one-tile rules, same box
+python "$ROOT/tools/batch_sweep.py" > "$OUT/${R}_batch_size_sweep.txt" 2> "$OUT/${R}_batch_size_sweep.err"
+NS_PLAN=0 python "$ROOT/tools/batch_sweep.py" > "$OUT/${R}_batch_size_sweep_plan0.txt" 2>> "$OUT/${R}_batch_size_sweep.err"
+python "$ROOT/tools/batch_sweep.py" --ragged --batches 4,8,12,16,24,32 > "$OUT/${R}_batch_size_sweep_ragged.txt" 2>> "$OUT/${R}_batch_size_sweep.err"
+NS_PACKED=0 python "$ROOT/tools/batch_sweep.py" --ragged --batches 4,8,12,16,24,32 > "$OUT/${R}_batch_size_sweep_ragged_grid.txt" 2>> "$OUT/${R}_batch_size_sweep.err"
+# per-launch view of two batch sizes that sit between steps (B = 9, B = 20)
+bash "$ROOT/tools/trace_batches.sh" ${R}_tb 9 20 > "$OUT/${R}_tb.log" 2>&1
 # rocprofv3's own per-kernel summary of the config-2 run, as it wrote it
 find "$OUT/${R}_trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/${R}_rocprofv3_kernel_stats.csv" \;
 
@@ -54,5 +61,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/${R}_write_cfg1_single" -o t 
 python "$ROOT/bench.py" --matmul bf16x3 --no-cpu-baseline > "$OUT/${R}_bench_bf16x3.log" 2>&1
 tail -1 "$OUT/${R}_bench_bf16x3.log" > "$OUT/${R}_bench_bf16x3.json"
 rocprofv3 --kernel-trace --stats --output-format rocpd csv -d "$OUT/${R}_trace_bf16x3" -o t -- python $ROOT/bench.py --matmul bf16x3 --steps 5 --warmup 2 --no-extras > "$OUT/${R}_trace_bf16x3.log" 2>&1
+# the long randomized parity run (the -m gpu suite holds a time-boxed slice of it: tests/test_gpu_stress.py)
+python "$ROOT/tests/fuzz_gpu.py" --iters 360 --seed 41 > "$OUT/${R}_fuzz.txt" 2>&1
+python "$ROOT/tests/fuzz_gpu.py" --iters 40 --seed 42 --big >> "$OUT/${R}_fuzz.txt" 2>&1
 ls -d "$OUT"/${R}_*/ | head -40
 cat "$OUT/${R}_bench.json" | cut -c1-300

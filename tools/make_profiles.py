@@ -52,7 +52,8 @@ rows = con.execute("select start, end, grid_x / workgroup_x as wgs from kernels 
 if rows:
     big = max(r[2] for r in rows)
     durs = [(r[1] - r[0]) / 1e3 for r in rows if r[2] == big]
-    n = int(under["roofline"]["launches"])
+    # the timed region of the traced run = its last `steps` forwards (bench.py's events sample every 5th of them since round 4)
+    n = max(1, len(durs) // max(1, (under["steps"] + under["warmup"]))) * int(under["steps"])
     timed = durs[-n:]
     under["rocprofv3_same_launches"] = {"kernel_workgroups": int(big), "launches": len(timed),
                                         "avg_us": round(sum(timed) / len(timed), 1),
@@ -84,8 +85,8 @@ if rows:
                  f"| every launch of the trace (warm-up forwards included) | {a['all_traced_launches']['n']} | {a['all_traced_launches']['avg_us']} | {a['all_traced_launches']['frac']:.3f} |\n"
                  f"| the timed region of the traced run (what bench.py's roofline covers) | {a['timed_region_only']['n']} | {a['timed_region_only']['avg_us']} | {a['timed_region_only']['frac']:.3f} |\n"
                  f"| the last forward of the trace | {a['last_forward']['n']} | {a['last_forward']['avg_us']} | {a['last_forward']['frac']:.3f} |\n"
-                 f"| bench.py's HIP events around the same launches, same (profiled) process | {a['timed_region_only']['n']} | {a['hip_events_in_bench_same_process']['avg_us']} | {a['hip_events_in_bench_same_process']['frac']:.3f} |\n"
-                 f"| bench.py's HIP events, UNPROFILED run (`{ROUND}_bench.json`: the figure on the driver's line) | {bench['roofline']['launches']} | {a['unprofiled_bench_hip_events']['avg_us']} | {a['unprofiled_bench_hip_events']['frac']:.3f} |\n\n"
+                 f"| bench.py's own events in the same (profiled) process: it times every 5th forward of its timed region, under the trace the FIRST timed forward only | {under['roofline']['launches']} | {a['hip_events_in_bench_same_process']['avg_us']} | {a['hip_events_in_bench_same_process']['frac']:.3f} |\n"
+                 f"| bench.py's events (on the dispatch packets), UNPROFILED run (`{ROUND}_bench.json`: `roofline.frac` on the driver's line; `roofline.frac_rocprof` is the second row) | {bench['roofline']['launches']} | {a['unprofiled_bench_hip_events']['avg_us']} | {a['unprofiled_bench_hip_events']['frac']:.3f} |\n\n"
                  f"Launch-order view, average per forward (us): {', '.join(str(x) for x in a['per_forward_avg_us_in_launch_order'])} "
                  f"(min {a['min_us']}, max {a['max_us']}).  The spread inside one trace is the order of the forwards, not noise: the first "
                  "forwards after the process starts run the same kernel slower and the figure settles over the following ones (the chip raises "
@@ -115,6 +116,15 @@ if lp:
 json.dump({"bench": bench, "bench_under_kernel_trace": under}, open(f"profiles/{ROUND}_bench.json", "w"), indent=1)
 
 # the other BASELINE configs (kernel trace only) and the opt-in bf16x3 mode
+for fn in ("batch_size_sweep", "batch_size_sweep_plan0", "batch_size_sweep_ragged", "batch_size_sweep_ragged_grid", "fuzz"):
+    src = f"{G}/{ROUND}_{fn}.txt"
+    if os.path.exists(src):
+        txt = "".join(l for l in open(src) if "amdgpu.ids" not in l)
+        open(f"profiles/{ROUND}_{fn}.txt", "w").write(txt)
+for b in (9, 20):  # per-launch sequences of two batch sizes that sit between steps
+    src = f"{G}/{ROUND}_tb_b{b}.seq.txt"
+    if os.path.exists(src):
+        shutil.copy(src, f"profiles/{ROUND}_launch_sequence_b{b}.txt")
 for wl in ("cfg1_single", "cfg4_d512", "cfg5_longform", "cfg5_longform_gaussian", "bf16x3",
            "cfg2_b16_ragged_packed", "cfg2_b16_ragged_grid", "cfg5_longform_ragged_packed", "cfg5_longform_ragged_grid"):
     db = f"{G}/{ROUND}_trace_{wl}/t_results.db"
@@ -159,6 +169,9 @@ d = {
     "note": "FETCH_SIZE counts the L2's fabric-side requests (Infinity-Cache hits included); the 9.4 MB weight matrix is fetched once per XCD (8x = 75 MB), the activation rows once",
     "mfma_util_pct": round(100 * busy / ((gui / 8) * 1024), 2), "clock_ghz_under_pmc": round(gui / 8 / (dur * 1e-6) / 1e9, 3),
     "mfma_flops_executed": m[(kname, wgs, "SQ_INSTS_VALU_MFMA_MOPS_F32")][0] * 512, "avg_duration_us_under_pmc": dur,
+    # the same launches in the round's rocprofv3 kernel trace, timed region only (bench.py reports roofline.frac_rocprof from it)
+    "rocprof_timed_avg_us": under.get("dominant_kernel_averages", {}).get("timed_region_only", {}).get("avg_us"),
+    "rocprof_source": f"profiles/{ROUND}_kernel_stats.md (Dominant kernel: one number per claim)",
 }
 json.dump(d, open("profiles/dominant_kernel_traffic.json", "w"), indent=1)
 
