@@ -10,9 +10,10 @@
  * in a caller-provided arena and every call takes a caller-provided workspace
  * (PyTorch is only the allocator / stream owner on the Python side).
  *
- * THREADING.  One ns_model serves ONE host thread at a time: the forward keeps per-call state (the packed-row context,
- * the measurement slots, the row count of the last forward) in the model / in thread-local storage while it enqueues its
- * launches.  Calls on the same model from two host threads must be serialised by the caller; different models (one per
+ * THREADING.  One ns_model serves ONE host thread at a time: the model carries per-call state — the measurement slots of
+ * ns_profile_enable and the row counts ns_last_phase1_rows / ns_last_phase2_rows report — that a forward writes while it
+ * enqueues its launches (everything else a forward needs, the packed-row context included, lives in the caller's
+ * workspaces).  Calls on the same model from two host threads must be serialised by the caller; different models (one per
  * thread, or one per process as bench.py does per GPU) are independent, and one thread may drive several HIP streams
  * with one model as long as each stream has its own workspaces.  ns_last_error() is per thread.  This matches the
  * reference's caller: single-threaded, synchronous, one module instance (synthesize.py:59-76).
@@ -209,6 +210,17 @@ int ns_op_ffn_conv1(ns_model* m, const char* prefix, const float* x, int B, int 
  * (single-utterance latency); 8 * (B*S*H*dk + 2*B*S*H) floats always suffice. */
 int ns_op_attention_core(const float* qkv, const int64_t* lens, int B, int S, int H, int dk, float* out, void* scratch,
                          size_t scratch_bytes, void* stream);
+
+/* Introspection of the step-aware launch plan (csrc/gemm_conv.hip plan_rows, csrc/attention.hip plan_key_split); host-side, no GPU
+ * needed.  ns_plan_gemm: how a plain Conv1D-as-GEMM of M rows, N output channels, kernel size KW over Cin input channels
+ * (transformer/SubLayers.py:87-95 over an arbitrary B*T) is launched: out = {BM, BN, rows} of the main launch and {BM, BN, rows} of
+ * the remainder launch (zeros: a single launch).  Returns 1 when the planner covers the shape, 0 when it is left to the small-grid
+ * K-split ladder (few tiles) or the narrow-channel rules (then out is zeroed).  Every planner tile sums a row's contraction in the
+ * same order, so the cut never shows in the bits.
+ * ns_plan_attention_split: key ranges per 128-query tile of a dense attention launch (1 = none; 16 = the small-grid paths' own
+ * sizing, the value the workspace is reserved for). */
+int ns_plan_gemm(int M, int N, int Cin, int KW, int32_t out[6]);
+int ns_plan_attention_split(int B, int S, int H, int dk);
 
 /* Measurement hook for bench.py's roofline legs: while enabled, the launches of the three heaviest kernels inside
  * ns_forward_mel carry hipEvents ON THEIR OWN DISPATCH PACKETS (hipExtLaunchKernel start / stop events: the kernel's begin and

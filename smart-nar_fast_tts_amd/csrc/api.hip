@@ -57,13 +57,14 @@ struct ns_model {
   const float* P(size_t off) const { return arena + off; }
   // optional HIP-event timing of the three heaviest launch groups inside the real forward (bench.py's roofline legs):
   // slot 0 = FFN w_1 (k=9 Conv1D-as-GEMM, the dominant kernel), 1 = fused attention, 2 = PostNet 512->512 k=5 layers.
-  // Measurement state, not model state: mutable so that the (const) forward helpers can record into it.
+  // Measurement state: the only per-call state the MODEL carries (with the two row counts below) — the packed-row context of a
+  // forward travels in its Scratch, not in a global — which is why one model serves one host thread at a time (nar_fs2.h).
   struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double flops = 0.0; };
-  mutable long long last_rows = 0;  // rows phase 2 of the most recent ns_forward_mel[_packed] ran on (B*T, or the packed windows)
-  mutable long long last_rows1 = 0; // rows phase 1 of the most recent ns_forward_durations[_packed] ran on (B*L, or the packed phoneme rows)
-  mutable unsigned prof = 0;  // bit i: slot i is timed (ns_profile_enable)
-  mutable bool prof_active = false;
-  mutable ProfSlot prof_slot[NS_PROFILE_SLOTS];
+  long long last_rows = 0;  // rows phase 2 of the most recent ns_forward_mel[_packed] ran on (B*T, or the packed windows)
+  long long last_rows1 = 0; // rows phase 1 of the most recent ns_forward_durations[_packed] ran on (B*L, or the packed phoneme rows)
+  unsigned prof = 0;  // bit i: slot i is timed (ns_profile_enable)
+  bool prof_active = false;
+  ProfSlot prof_slot[NS_PROFILE_SLOTS];
 };
 
 static const char* kPredNames[3] = {"duration", "pitch", "energy"};
@@ -416,7 +417,10 @@ struct Bump {
 // every ticketed launch then takes its own slice — no reset, no reuse inside a phase
 constexpr int TICKET_INTS = 16384;
 
+struct PackedCtx { RowMap rm; int Mp; };
+
 struct Scratch {  // per-stack temporaries for M rows
+  const PackedCtx* pk;  // packed-row context of the phase this scratch serves (see cur_rm below); nullptr = dense grid
   float *xa, *xb, *qkv, *att, *t1, *x1, *hid, *vp1, *vp2, *pos_ext, *att_part;
   size_t att_part_floats;
   int* tickets; int tickets_used;
@@ -432,6 +436,7 @@ static size_t imax(size_t a, size_t b) { return a > b ? a : b; }
 
 static Scratch carve(const ns_config& c, Bump& bp, size_t M, int S, bool no_split = false) {
   Scratch s;
+  s.pk = nullptr;
   const size_t d = c.d_enc;
   s.xa = bp.f(M * d); s.xb = bp.f(M * d);
   s.qkv = bp.f(M * 3 * d); s.att = bp.f(M * d); s.t1 = bp.f(M * d); s.x1 = bp.f(M * d);
@@ -487,19 +492,13 @@ static int check_ready(const ns_model* m) {
   return 0;
 }
 
-// Packed rows (kernels.h RowMap): set by the packed phase-2 forward around its launch sequence; every GEMM, row kernel and
-// attention launch issued meanwhile on this thread addresses rows through the map, and "B utterances of S rows" means the
-// Mp packed rows.  nullptr = the dense [B, S] grid.
-struct PackedCtx { RowMap rm; int Mp; };
-static thread_local const PackedCtx* tl_pk = nullptr;
-struct PackedScope {
-  explicit PackedScope(const PackedCtx* pk) { tl_pk = pk; }
-  ~PackedScope() { tl_pk = nullptr; }
-};
-static const RowMap* cur_rm() { return tl_pk ? &tl_pk->rm : nullptr; }
-static int rows_of(int B, int S) { return tl_pk ? tl_pk->Mp : B * S; }
+// Packed rows (kernels.h RowMap): a forward that runs a phase on packed rows hangs its context on that phase's Scratch (sc.pk);
+// every GEMM, row kernel and attention launch issued with that Scratch addresses rows through the map, and "B utterances of S
+// rows" means the Mp packed rows.  nullptr = the dense [B, S] grid.
+static const RowMap* cur_rm(const Scratch& sc) { return sc.pk ? &sc.pk->rm : nullptr; }
+static int rows_of(const Scratch& sc, int B, int S) { return sc.pk ? sc.pk->Mp : B * S; }
 
-static int gemm(const float* X, int ldx, const float* W, const float* bias, const float* resid, int ldr, float* Y, int ldy,
+static int gemm(const Scratch& sc, const float* X, int ldx, const float* W, const float* bias, const float* resid, int ldr, float* Y, int ldy,
                 int M, int N, int Cin, int KW, int S, int act, hipStream_t st, const RowEpilogue* epi = nullptr, int epi_mode = EPI_NONE,
                 const unsigned short* Wb3 = nullptr, const LaunchTiming* tm = nullptr) {
   ConvGemm p;
@@ -508,7 +507,7 @@ static int gemm(const float* X, int ldx, const float* W, const float* bias, cons
   p.M = M; p.N = N; p.Cin = Cin; p.KW = KW; p.pad = (KW - 1) / 2; p.S = S; p.act = act;
   p.epi = epi ? epi_mode : EPI_NONE;
   if (epi) p.e = *epi;
-  if (tl_pk) { p.rm = tl_pk->rm; p.e.row_b = tl_pk->rm.row_b; p.e.row_t = tl_pk->rm.row_t; }
+  if (sc.pk) { p.rm = sc.pk->rm; p.e.row_b = sc.pk->rm.row_b; p.e.row_t = sc.pk->rm.row_t; }
   // opt-in bf16x3 planes exist for this weight AND the launch is large enough for the 128-row tiles: split-bf16 matrix cores
   if (Wb3 && conv_gemm_b3_ok(M, N, Cin, KW, p.epi)) {
     p.Wb3 = Wb3;
@@ -540,20 +539,20 @@ static int gemm_ln(const float* X, int ldx, const float* W, const float* bias, c
   memset(&e, 0, sizeof(e));
   e.ln_g = g; e.ln_b = b; e.lens = lens;
   if (Wb3 && !conv_gemm_b3_ok(M, N, Cin, KW, EPI_LN) && conv_gemm_b3_ok(M, N, Cin, KW, EPI_NONE)) {
-    NS_TRY(gemm(X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st, nullptr, EPI_NONE, Wb3));
-    NS_HIP(launch_layernorm(tmp, g, b, Y, M, N, S, lens, st, cur_rm()));
+    NS_TRY(gemm(sc, X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st, nullptr, EPI_NONE, Wb3));
+    NS_HIP(launch_layernorm(tmp, g, b, Y, M, N, S, lens, st, cur_rm(sc)));
     return 0;
   }
   // (64x64 tiles with the ticketed epilogue in place of the full-row tile when its steps of 256 tiles fit the row count badly
   //  were measured in round 4 and lose: at 572 workgroups the last arrivers' row work costs +12 us for a LayerNorm and +25 us
   //  for a predictor tail, more than the finer steps save — B = 9: conv+LN 57 vs 56 us, conv+tail 80-86 vs 62, w_2 70.7 vs 70)
-  if (fuse_row_epilogue(M, N, Cin)) return gemm(X, ldx, W, bias, resid, N, Y, N, M, N, Cin, KW, S, act, st, &e, EPI_LN, Wb3);
+  if (fuse_row_epilogue(M, N, Cin)) return gemm(sc, X, ldx, W, bias, resid, N, Y, N, M, N, Cin, KW, S, act, st, &e, EPI_LN, Wb3);
   if (conv_gemm_ticket_ok(M, N, Cin) && (e.ticket = sc.take_tickets(conv_gemm_ticket_ints(M))) != nullptr) {
     e.y_out = Y;
-    return gemm(X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st, &e, EPI_LN);
+    return gemm(sc, X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st, &e, EPI_LN);
   }
-  NS_TRY(gemm(X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st));
-  NS_HIP(launch_layernorm(tmp, g, b, Y, M, N, S, lens, st, cur_rm()));
+  NS_TRY(gemm(sc, X, ldx, W, bias, resid, N, tmp, N, M, N, Cin, KW, S, act, st));
+  NS_HIP(launch_layernorm(tmp, g, b, Y, M, N, S, lens, st, cur_rm(sc)));
   return 0;
 }
 
@@ -562,9 +561,9 @@ static int gemm_ln(const float* X, int ldx, const float* W, const float* bias, c
 // (kernels.h LaunchTiming): no marker packet, no gap on the stream — marker pairs around the 11 timed launches of a forward
 // cost it ~130 us (3 % at config 2, round 3's bench line paid that inside its timed region).
 struct ProfScope {
-  const ns_model* m; int slot; double flops; bool on;
+  ns_model* m; int slot; double flops; bool on;
   LaunchTiming tm{nullptr, nullptr};
-  ProfScope(const ns_model* m_, int slot_, double flops_) : m(m_), slot(slot_), flops(flops_), on(m_->prof_active && ((m_->prof >> slot_) & 1u)) {}
+  ProfScope(ns_model* m_, int slot_, double flops_) : m(m_), slot(slot_), flops(flops_), on(m_->prof_active && ((m_->prof >> slot_) & 1u)) {}
   int begin() {
     if (!on) return 0;
     ns_model::ProfSlot& ps = m->prof_slot[slot];
@@ -587,16 +586,16 @@ struct ProfScope {
 };
 
 // MultiHeadAttention.forward (transformer/SubLayers.py:29-59); out = LayerNorm(fc(attn) + x), masked when mask_rows
-static int mha(const ns_model* m, const LayerW& L, int d, int H, const float* x, const long long* lens, int B, int S,
+static int mha(ns_model* m, const LayerW& L, int d, int H, const float* x, const long long* lens, int B, int S,
                float* out, bool mask_rows, Scratch& sc, hipStream_t st) {
-  const int M = rows_of(B, S);
+  const int M = rows_of(sc, B, S);
   auto b3 = [&](size_t off) { return off != NO_B3 ? reinterpret_cast<const unsigned short*>(m->P(off)) : nullptr; };
-  NS_TRY(gemm(x, d, m->P(L.qkv_w), m->P(L.qkv_b), nullptr, 0, sc.qkv, 3 * d, M, 3 * d, d, 1, S, ACT_NONE, st, nullptr, EPI_NONE, b3(L.qkv_b3)));
+  NS_TRY(gemm(sc, x, d, m->P(L.qkv_w), m->P(L.qkv_b), nullptr, 0, sc.qkv, 3 * d, M, 3 * d, d, 1, S, ACT_NONE, st, nullptr, EPI_NONE, b3(L.qkv_b3)));
   {
     ProfScope ps(m, 1, 4.0 * (double)M * (double)S * (double)d);
     NS_TRY(ps.begin());
     NS_HIP(launch_attention(sc.qkv, lens, B, S, H, d / H, sc.att, sc.att_part, sc.att_part_floats,
-                            (sc.att_part && !tl_pk) ? sc.take_tickets(attention_ticket_ints(B, S, H)) : nullptr, st, cur_rm(), ps.timing()));
+                            (sc.att_part && !sc.pk) ? sc.take_tickets(attention_ticket_ints(B, S, H)) : nullptr, st, cur_rm(sc), ps.timing()));
     ps.end();
   }
   return gemm_ln(sc.att, d, m->P(L.fc_w), m->P(L.fc_b), x, sc.t1, out, M, d, d, 1, S, ACT_NONE, m->P(L.ln1_g), m->P(L.ln1_b),
@@ -604,14 +603,14 @@ static int mha(const ns_model* m, const LayerW& L, int d, int H, const float* x,
 }
 
 // PositionwiseFeedForward.forward (transformer/SubLayers.py:87-95)
-static int ffn(const ns_model* m, const LayerW& L, int d, const float* x, const long long* lens, int B, int S, float* out,
+static int ffn(ns_model* m, const LayerW& L, int d, const float* x, const long long* lens, int B, int S, float* out,
                bool mask_rows, Scratch& sc, hipStream_t st) {
   const ns_config& c = m->cfg;
-  const int M = rows_of(B, S);
+  const int M = rows_of(sc, B, S);
   {
     ProfScope ps(m, 0, 2.0 * (double)M * (double)c.ffn_k1 * (double)d * (double)c.d_inner);
     NS_TRY(ps.begin());
-    NS_TRY(gemm(x, d, m->P(L.w1), m->P(L.w1_b), nullptr, 0, sc.hid, c.d_inner, M, c.d_inner, d, c.ffn_k1, S, ACT_RELU, st, nullptr, EPI_NONE,
+    NS_TRY(gemm(sc, x, d, m->P(L.w1), m->P(L.w1_b), nullptr, 0, sc.hid, c.d_inner, M, c.d_inner, d, c.ffn_k1, S, ACT_RELU, st, nullptr, EPI_NONE,
                 L.w1_b3 != NO_B3 ? reinterpret_cast<const unsigned short*>(m->P(L.w1_b3)) : nullptr, ps.timing()));
     ps.end();
   }
@@ -621,7 +620,7 @@ static int ffn(const ns_model* m, const LayerW& L, int d, const float* x, const 
 }
 
 // FFTBlock.forward (transformer/Layers.py:39-48): both masked_fill's are fused into the LayerNorm kernels
-static int fft_block(const ns_model* m, const LayerW& L, int d, int H, const float* x, const long long* lens, int B, int S,
+static int fft_block(ns_model* m, const LayerW& L, int d, int H, const float* x, const long long* lens, int B, int S,
                      float* out, Scratch& sc, hipStream_t st) {
   NS_TRY(mha(m, L, d, H, x, lens, B, S, sc.x1, true, sc, st));
   NS_TRY(ffn(m, L, d, sc.x1, lens, B, S, out, true, sc, st));
@@ -645,7 +644,7 @@ static int predictor(const ns_model* m, const PredW& w, const float* x, const lo
                      float* pred, const float* bins, const float* emb, const float* pos, float* x_out, Scratch& sc,
                      hipStream_t st) {
   const ns_config& c = m->cfg;
-  const int M = rows_of(B, S), F = c.vp_filter;
+  const int M = rows_of(sc, B, S), F = c.vp_filter;
   // conv1d_1 -> relu -> layer_norm_1 (no mask between the layers: model/modules.py:245-274)
   NS_TRY(gemm_ln(x, w.cin, m->P(w.c1), m->P(w.c1_b), nullptr, sc.vp1, sc.vp2, M, F, w.cin, c.vp_kernel, S, ACT_RELU, m->P(w.ln1_g),
                  m->P(w.ln1_b), nullptr, sc, st));
@@ -657,19 +656,19 @@ static int predictor(const ns_model* m, const PredW& w, const float* x, const lo
   e.control = control; e.target = target; e.bins = bins; e.n_edges = c.n_bins - 1; e.emb = emb; e.x_in = x; e.pos = pos; e.x_out = x_out;
   e.D = w.cin;
   if (fuse_row_epilogue(M, F, F))
-    return gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, nullptr, F, M, F, F, c.vp_kernel, S, ACT_RELU, st, &e, EPI_LN_PRED);
+    return gemm(sc, sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, nullptr, F, M, F, F, c.vp_kernel, S, ACT_RELU, st, &e, EPI_LN_PRED);
   if (conv_gemm_ticket_ok(M, F, F) && (e.ticket = sc.take_tickets(conv_gemm_ticket_ints(M))) != nullptr)
-    return gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st, &e, EPI_LN_PRED);
-  NS_TRY(gemm(sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st));
+    return gemm(sc, sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st, &e, EPI_LN_PRED);
+  NS_TRY(gemm(sc, sc.vp2, F, m->P(w.c2), m->P(w.c2_b), nullptr, 0, sc.vp1, F, M, F, F, c.vp_kernel, S, ACT_RELU, st));
   NS_HIP(launch_ln_linear_embed(sc.vp1, m->P(w.ln2_g), m->P(w.ln2_b), m->P(w.lin_w), m->P(w.lin_b), pred, M, F, S, lens,
-                                control, target, bins, c.n_bins, emb, x, pos, x_out, w.cin, st, cur_rm()));
+                                control, target, bins, c.n_bins, emb, x, pos, x_out, w.cin, st, cur_rm(sc)));
   return 0;
 }
 
 // PostNet.forward (transformer/Layers.py:169-177); resid != nullptr adds `+ output` of fastspeech2_align.py:85
-static int postnet(const ns_model* m, const float* mel, int B, int T, const float* resid, float* out, Scratch& sc, hipStream_t st) {
+static int postnet(ns_model* m, const float* mel, int B, int T, const float* resid, float* out, Scratch& sc, hipStream_t st) {
   const ns_config& c = m->cfg;
-  const int M = rows_of(B, T);
+  const int M = rows_of(sc, B, T);
   float* ping = sc.hid;
   float* pong = sc.hid + (size_t)M * c.postnet_dim;
   const float* cur = mel;
@@ -681,7 +680,7 @@ static int postnet(const ns_model* m, const float* mel, int B, int T, const floa
     const bool mid = w.cin == c.postnet_dim && w.cout == c.postnet_dim;
     ProfScope ps(m, 2, 2.0 * (double)M * (double)c.postnet_k * (double)w.cin * (double)w.cout);
     if (mid) NS_TRY(ps.begin());
-    NS_TRY(gemm(cur, ld, m->P(w.w), m->P(w.b), last ? resid : nullptr, c.n_mel, dst, w.cout, M, w.cout, w.cin, c.postnet_k, T,
+    NS_TRY(gemm(sc, cur, ld, m->P(w.w), m->P(w.b), last ? resid : nullptr, c.n_mel, dst, w.cout, M, w.cout, w.cin, c.postnet_k, T,
                 last ? ACT_NONE : ACT_TANH, st, nullptr, EPI_NONE,
                 w.w_b3 != NO_B3 ? reinterpret_cast<const unsigned short*>(m->P(w.w_b3)) : nullptr, mid ? ps.timing() : nullptr));
     if (mid) ps.end();
@@ -705,15 +704,15 @@ static int postnet_constants(ns_model* m, hipStream_t st) {
   return postnet(m, in, 1, PN_CONST_ROWS, in, m->arena + m->pn_const, sc, st);
 }
 
-static int encoder(const ns_model* m, const long long* texts, const long long* lens, int B, int L, float* out, Scratch& sc,
+static int encoder(ns_model* m, const long long* texts, const long long* lens, int B, int L, float* out, Scratch& sc,
                    hipStream_t st) {
   const ns_config& c = m->cfg;
-  const int M = rows_of(B, L), d = c.d_enc;
+  const int M = rows_of(sc, B, L), d = c.d_enc;
   const float* pos;
   NS_TRY(position_rows(m, m->enc_pos, L, d, sc, &pos, st));
   float* cur = m->enc.empty() ? out : sc.xa;
   // (+ zeroes the phase's tickets)
-  if (tl_pk) NS_HIP(launch_embed_pos_packed(texts, m->P(m->emb), pos, cur, tl_pk->rm, B, M, L, d, c.n_vocab, sc.tickets, TICKET_INTS, st));
+  if (sc.pk) NS_HIP(launch_embed_pos_packed(texts, m->P(m->emb), pos, cur, sc.pk->rm, B, M, L, d, c.n_vocab, sc.tickets, TICKET_INTS, st));
   else NS_HIP(launch_embed_pos(texts, m->P(m->emb), pos, cur, M, L, d, c.n_vocab, sc.tickets, TICKET_INTS, st));
   for (size_t i = 0; i < m->enc.size(); ++i) {
     float* dst = (i + 1 == m->enc.size()) ? out : (cur == sc.xa ? sc.xb : sc.xa);
@@ -724,7 +723,7 @@ static int encoder(const ns_model* m, const long long* texts, const long long* l
 }
 
 // MelDecoder's layer stack on an input that already carries the position rows
-static int decoder_stack(const ns_model* m, float* x, const long long* lens, int B, int T, float* out, Scratch& sc, hipStream_t st) {
+static int decoder_stack(ns_model* m, float* x, const long long* lens, int B, int T, float* out, Scratch& sc, hipStream_t st) {
   const ns_config& c = m->cfg;
   float* cur = x;
   float* alt = (x == sc.xa) ? sc.xb : sc.xa;
@@ -733,7 +732,7 @@ static int decoder_stack(const ns_model* m, float* x, const long long* lens, int
     NS_TRY(fft_block(m, m->dec[i], c.d_dec, c.n_dec_head, cur, lens, B, T, dst, sc, st));
     if (dst != out) { alt = cur; cur = dst; }
   }
-  if (m->dec.empty() && out != x) NS_HIP(hipMemcpyAsync(out, x, (size_t)rows_of(B, T) * c.d_dec * 4, hipMemcpyDeviceToDevice, st));
+  if (m->dec.empty() && out != x) NS_HIP(hipMemcpyAsync(out, x, (size_t)rows_of(sc, B, T) * c.d_dec * 4, hipMemcpyDeviceToDevice, st));
   return 0;
 }
 
@@ -815,7 +814,7 @@ static int forward_durations(ns_model* m, const int64_t* texts, const int64_t* s
     NS_HIP(launch_pack_plan_only(lens, B, L, c.n_enc_head, M, plan, &pk.rm, st, PHONEME_GUARD));  // (row maps: the embedding kernel)
   }
   {
-    PackedScope scope(packed ? &pk : nullptr);
+    sc.pk = packed ? &pk : nullptr;
     NS_TRY(encoder(m, (const long long*)texts, lens, B, L, enc_w, sc, st));
     NS_TRY(predictor(m, m->pred[0], enc_w, lens, B, L, 1.0f, nullptr, logd_w, nullptr, nullptr, nullptr, nullptr, sc, st));
     // phoneme_level features are predicted on the encoder output, before the length regulator, pitch first, and
@@ -973,7 +972,7 @@ static int forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens
   } else {
     NS_HIP(launch_length_regulate(enc_out, cum, B, L, c.d_enc, T, sc.xa, mel_mask, lens, status, sc.tickets, TICKET_INTS, st));  // + mel mask, status, ticket zeroing
   }
-  PackedScope scope(packed ? &pk : nullptr);
+  sc.pk = packed ? &pk : nullptr;
   float* const mel_dst = packed ? mel_p : mel;
   float* const post_dst = packed ? post_p : postnet_mel;
   float* const pp_dst = packed ? pp_p : p_pred;
@@ -997,13 +996,13 @@ static int forward_mel(ns_model* m, int B, int L, int T, const int64_t* mel_lens
     float* t = cur; cur = alt; alt = t;
   }
   if (!c.pitch_frame_level && !c.energy_frame_level) {
-    NS_HIP(launch_add_pos(cur, pos, alt, M, T, d, st, cur_rm()));
+    NS_HIP(launch_add_pos(cur, pos, alt, M, T, d, st, cur_rm(sc)));
     float* t = cur; cur = alt; alt = t;
   }
   m->prof_active = m->prof != 0;  // time only phase 2's launches: one shape per slot (the encoder runs the same kernels at B*L rows)
   int rc = decoder_stack(m, cur, lens, B, T, sc.att, sc, st);
   // note: decoder_stack's last layer writes into sc.att only after its own attention output was consumed
-  if (!rc) rc = gemm(sc.att, d, m->P(m->mel_w), m->P(m->mel_b), nullptr, 0, mel_dst, c.n_mel, M, c.n_mel, d, 1, T, ACT_NONE, st);
+  if (!rc) rc = gemm(sc, sc.att, d, m->P(m->mel_w), m->P(m->mel_b), nullptr, 0, mel_dst, c.n_mel, M, c.n_mel, d, 1, T, ACT_NONE, st);
   if (!rc) rc = postnet(m, mel_dst, B, T, mel_dst, post_dst, sc, st);
   m->prof_active = false;
   if (!rc && packed) {
@@ -1129,6 +1128,14 @@ extern "C" int ns_op_variance_embedding(ns_model* m, int which, const float* x, 
   return predictor(m, m->pred[1 + which], x, (const long long*)lens, B, S, control, target, pred, m->P(bins), m->P(emb), nullptr, x_out,
                    sc, st);
 }
+extern "C" int ns_plan_gemm(int M, int N, int Cin, int KW, int32_t out[6]) {
+  int o[6] = {0, 0, 0, 0, 0, 0};
+  const bool planned = conv_gemm_plan(M, N, Cin, KW, o);
+  if (out) for (int i = 0; i < 6; ++i) out[i] = planned ? o[i] : 0;
+  return planned ? 1 : 0;
+}
+extern "C" int ns_plan_attention_split(int B, int S, int H, int dk) { return attention_split(B, S, H, dk); }
+
 extern "C" int ns_profile_enable(ns_model* m, int on) {
   if (!m) return fail("ns_profile_enable: null model");
   const bool keep = on > 0 && (on & NS_PROFILE_KEEP) != 0;  // change the set of timed slots, keep what was recorded so far
@@ -1180,7 +1187,9 @@ extern "C" int ns_op_mel_decoder(ns_model* m, const float* x, const int64_t* len
 extern "C" int ns_op_mel_linear(ns_model* m, const float* x, int B, int T, float* out, void* stream) {
   NS_TRY(check_ready(m));
   const ns_config& c = m->cfg;
-  return gemm(x, c.d_dec, m->P(m->mel_w), m->P(m->mel_b), nullptr, 0, out, c.n_mel, B * T, c.n_mel, c.d_dec, 1, T, ACT_NONE,
+  Scratch sc;
+  memset(&sc, 0, sizeof(sc));  // (a plain GEMM on the dense grid: no temporaries, no packed context)
+  return gemm(sc, x, c.d_dec, m->P(m->mel_w), m->P(m->mel_b), nullptr, 0, out, c.n_mel, B * T, c.n_mel, c.d_dec, 1, T, ACT_NONE,
               (hipStream_t)stream);
 }
 extern "C" int ns_op_postnet(ns_model* m, const float* mel, int B, int T, float* out, void* ws, size_t ws_bytes, void* stream) {
@@ -1208,6 +1217,8 @@ extern "C" int ns_op_ffn_conv1(ns_model* m, const char* prefix, const float* x, 
   const LayerW* L; int d, H;
   NS_TRY(find_layer(m, prefix, &L, &d, &H, ".pos_ffn"));
   const ns_config& c = m->cfg;
-  return gemm(x, d, m->P(L->w1), m->P(L->w1_b), nullptr, 0, hidden, c.d_inner, B * S, c.d_inner, d, c.ffn_k1, S, ACT_RELU,
+  Scratch sc;
+  memset(&sc, 0, sizeof(sc));
+  return gemm(sc, x, d, m->P(L->w1), m->P(L->w1_b), nullptr, 0, hidden, c.d_inner, B * S, c.d_inner, d, c.ffn_k1, S, ACT_RELU,
               (hipStream_t)stream);
 }

@@ -492,12 +492,16 @@ struct RowPlan { int main_tile, main_rows, rem_tile; float us; };  // main_rows 
 static RowPlan plan_rows(long M, int N, int chunks) {
   constexpr float CUT_US = 3.0f;  // a second launch: its ramp is in a(tile), this is the boundary itself
   RowPlan best{-1, 0, T64, 1e30f};
-  for (int t = 0; t < N_TILES; ++t) {
+  // short contractions (QKV, fc: K = d, 8-16 chunks): prologue and epilogue weigh as much as the K loop, and three 64x128 workgroups
+  // per CU interleave them better than one tall 16-wave tile — settled by forward A/B in round 3 (config 2 5.476 -> 5.456 ms) and
+  // again by the model's own margin in round 4 (B = 20 QKV: 256x256 one step 83 us in the lab against 77 us on 64x128)
+  const int first = chunks <= 16 ? T64W : T256;
+  for (int t = first; t < N_TILES; ++t) {
     if (kTile[t].bn > N && t != T32 && t != T64N && t != T64) continue;  // (a 256-wide tile on a narrower output: never)
     const float c = tile_time(t, M, N, chunks);
     if (c < best.us) best = RowPlan{-1, 0, t, c};
   }
-  for (int t = T256; t <= T64; ++t) {
+  for (int t = first; t <= T64; ++t) {
     if (kTile[t].bn > N) continue;
     const long ntn = (N + kTile[t].bn - 1) / kTile[t].bn;
     const long per = (256 / ntn) * kTile[t].bm;  // rows of one full step
@@ -514,6 +518,19 @@ static RowPlan plan_rows(long M, int N, int chunks) {
     }
   }
   return best;
+}
+
+// the plan of a plain (no row epilogue) GEMM of this shape, for introspection (nar_fs2.h ns_plan_gemm): false = the shape is below
+// the planner's range (small-grid K-split ladder) or outside it (Cin % 32 != 0, N < 128), nothing is written
+bool conv_gemm_plan(int M, int N, int Cin, int KW, int out[6]) {
+  if (!launch_planner_enabled() || M <= 0 || N < 128 || Cin % 32 != 0) return false;
+  const long rows64 = ((long)M + 63) / 64;
+  if (rows64 * ((N + 127) / 128) <= 256) return false;
+  const RowPlan pl = plan_rows(M, N, KW * (Cin / 32));
+  const int mt = pl.main_rows ? pl.main_tile : pl.rem_tile;
+  out[0] = kTile[mt].bm; out[1] = kTile[mt].bn; out[2] = pl.main_rows ? pl.main_rows : M;
+  out[3] = pl.main_rows ? kTile[pl.rem_tile].bm : 0; out[4] = pl.main_rows ? kTile[pl.rem_tile].bn : 0; out[5] = pl.main_rows ? M - pl.main_rows : 0;
+  return true;
 }
 
 static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bool allow_split, const LaunchTiming* tm);

@@ -71,6 +71,7 @@ struct ConvGemm {
 // A plan of several launches gets `start` on its first and `stop` on its last kernel.  nullptr / {nullptr, nullptr} = untimed.
 struct LaunchTiming { hipEvent_t start, stop; };
 hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st, const LaunchTiming* tm = nullptr);
+bool conv_gemm_plan(int M, int N, int Cin, int KW, int out[6]);  // {bm, bn, rows} of the main launch, {bm, bn, rows} of the remainder (0 = none)
 // NS_PLAN=0 in the environment: the round-3 one-tile-per-launch rules (A/B runs of the planner; read once)
 bool launch_planner_enabled();
 // opt-in "bf16x3" precision mode (gemm_bf16x3.hip): same contraction from an exact 3-way bf16 split of both operands

@@ -352,3 +352,43 @@ def test_module_introspection_surface():
     assert isinstance(out, tuple) and len(out) == 12 and out[9] == 9 and out.check() == [] and tuple(out) == tuple(range(12))
     a, b, *rest = out
     assert (a, b) == (0, 1) and len(rest) == 10
+
+
+def test_launch_plan_invariants_and_settled_choices(lib):
+    """The step-aware launch plan (include/nar_fs2.h ns_plan_gemm / ns_plan_attention_split) is host logic: checked here without a
+    GPU.  Invariants for every row count: the launches cover exactly M rows, a cut falls on a whole number of the main tile's rows and
+    of its full steps of 256 workgroups, the remainder's tile is no taller than the main one.  And the choices that round 3 settled by
+    alternating whole-forward runs at the BASELINE configurations must come out of the cost model unchanged."""
+    _, lib = lib
+
+    def plan(M, N, Cin, KW):
+        o = (C.c_int32 * 6)()
+        return lib.ns_plan_gemm(M, N, Cin, KW, o), list(o)
+
+    shapes = [(1024, 256, 9), (512, 512, 5), (768, 256, 1), (256, 1024, 1)]  # FFN w_1, PostNet 512->512, QKV, FFN w_2 (plain form)
+    for N, Cin, KW in shapes:
+        for M in list(range(3000, 36000, 317)) + [8192, 8193, 16384, 16385, 65536 + 1088]:
+            ok, (bm, bn, rows, rbm, rbn, rrows) = plan(M, N, Cin, KW)
+            if not ok:
+                assert ((M + 63) // 64) * ((N + 127) // 128) <= 256, (M, N)
+                continue
+            assert rows + rrows == M and bm in (32, 64, 128, 256) and bn in (64, 128, 256), (M, N, bm, bn)
+            if rrows:
+                ntn = -(-N // bn)
+                per = (256 // ntn) * bm  # rows of one full step of the main tile
+                assert rows % per == 0 and rows % bm == 0 and rbm <= bm and rbm * rbn <= bm * bn, (M, N, bm, bn, rows, rbm, rbn, rrows)
+            if Cin * KW <= 512:
+                assert bm <= 64, ("short contractions stay on the 8-wave tiles", M, N, bm, bn)
+    # BASELINE configurations (B*T_pad rows): config 2, config 5, config 4
+    assert plan(16160, 1024, 256, 9) == (1, [256, 256, 16160, 0, 0, 0])      # FFN w_1: one round of the 256x256 tile
+    assert plan(16160, 512, 512, 5) == (1, [128, 256, 16160, 0, 0, 0])       # PostNet 512->512: one round of 128x256
+    assert plan(16160, 768, 256, 1) == (1, [64, 128, 16160, 0, 0, 0])        # QKV
+    assert plan(31248, 1024, 256, 9) == (1, [256, 256, 31248, 0, 0, 0])      # config 5: two rounds
+    ok, p4 = plan(66624, 1024, 512, 9)                                       # config 4: four full rounds + the remaining 1088 rows
+    assert ok and p4[:3] == [256, 256, 65536] and p4[5] == 1088 and p4[3] <= 64
+    # below the planner's range: the small-grid K-split ladder (encoder rows, single utterances)
+    assert plan(2048, 1024, 256, 9)[0] == 0 and plan(788, 512, 512, 5)[0] == 0 and plan(16160, 80, 512, 5)[0] == 0
+    # attention: one workgroup per CU -> a key split only when the last round of 256 fills badly
+    split = {B: lib.ns_plan_attention_split(B, 1010, 2, 128) for B in (9, 12, 16, 17, 20, 24, 32)}
+    assert split[16] == 1 and split[32] == 1 and split[9] == 3 and split[17] >= 4 and split[20] == 4 and split[24] == 2, split
+    assert lib.ns_plan_attention_split(1, 788, 2, 128) == 16 and lib.ns_plan_attention_split(64, 1041, 8, 64) == 1

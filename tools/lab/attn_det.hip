@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 #include "attention.hip"
+namespace ns { bool launch_planner_enabled() { return true; } }  // (defined in gemm_conv.hip, which this harness does not link)
 using namespace ns;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 int main() {
@@ -25,8 +26,8 @@ int main() {
     const size_t scr_floats = (size_t)ATT_SPLIT_MAX * ((size_t)s.B * s.S * d + 2 * (size_t)s.B * s.S * s.H);
     CK(hipMalloc(&scr, scr_floats * 4));
     CK(hipMemset(o1, 0xff, no * 4)); CK(hipMemset(o2, 0x7f, no * 4));
-    CK(launch_attention(q, dl, s.B, s.S, s.H, s.dk, o1, scr, scr_floats, 0));
-    CK(launch_attention(q, dl, s.B, s.S, s.H, s.dk, o2, scr, scr_floats, 0));
+    CK(launch_attention(q, dl, s.B, s.S, s.H, s.dk, o1, scr, scr_floats, nullptr, 0));
+    CK(launch_attention(q, dl, s.B, s.S, s.H, s.dk, o2, scr, scr_floats, nullptr, 0));
     CK(hipDeviceSynchronize());
     std::vector<float> a(no), b(no);
     CK(hipMemcpy(a.data(), o1, no * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), o2, no * 4, hipMemcpyDeviceToHost));

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <vector>
 #include "attention.hip"
+namespace ns { bool launch_planner_enabled() { return true; } }  // (defined in gemm_conv.hip, which this harness does not link)
 using namespace ns;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 int main() {
@@ -17,11 +18,11 @@ int main() {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   for (int k : {1, 2, 4, 8, 16, 24, 32}) {
     std::vector<long long> l(B, 32ll * k); CK(hipMemcpy(lens, l.data(), B * 8, hipMemcpyHostToDevice));
-    for (int i = 0; i < 3; ++i) CK(launch_attention(q, lens, B, S, H, dk, o, nullptr, 0, 0));
+    for (int i = 0; i < 3; ++i) CK(launch_attention(q, lens, B, S, H, dk, o, nullptr, 0, nullptr, 0));
     CK(hipDeviceSynchronize());
     float best = 1e9;
     for (int r = 0; r < 3; ++r) {
-      CK(hipEventRecord(a, 0)); for (int i = 0; i < 20; ++i) CK(launch_attention(q, lens, B, S, H, dk, o, nullptr, 0, 0));
+      CK(hipEventRecord(a, 0)); for (int i = 0; i < 20; ++i) CK(launch_attention(q, lens, B, S, H, dk, o, nullptr, 0, nullptr, 0));
       CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms / 20 < best ? ms / 20 : best;
     }
     printf("key tiles %2d   %7.1f us   (MFMA time at 2.4 GHz: %5.1f us)\n", k, best * 1e3, k * 128 * 64 / 2400.0);

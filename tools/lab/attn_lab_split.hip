@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 #include "attention.hip"
+namespace ns { bool launch_planner_enabled() { return true; } }  // (defined in gemm_conv.hip, which this harness does not link)
 using namespace ns;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 

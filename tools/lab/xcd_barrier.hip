@@ -27,7 +27,10 @@ __device__ __forceinline__ int xcc_id() {
   return v & 0xf;
 }
 
-// SCOPE 0: L2-local (workgroup-scope RMWs: no sc bits, resolved in this XCD's L2; polled with RMW + 0);  1: agent scope
+// SCOPE 0: L2-local (workgroup-scope RMWs: no sc bits, resolved in this XCD's L2).  Polled with a REAL read-modify-write,
+// fetch_max(counter, 0): `fetch_add(counter, 0)` is an idempotent RMW that LLVM turns into a plain atomic LOAD, and a
+// workgroup-scope load may be served by the CU's L1 forever (the first version of this harness timed out that way with >= 16
+// workgroups and passed with 8 by luck).  1: agent scope
 template <int SCOPE>
 __device__ __forceinline__ void bar(int* counter, int target, int* abort_flag) {
   __syncthreads();
@@ -35,7 +38,7 @@ __device__ __forceinline__ void bar(int* counter, int target, int* abort_flag) {
     long long t0 = wall_clock64();
     if (SCOPE == 0) {
       __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      while (__hip_atomic_fetch_add(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+      while (__hip_atomic_fetch_max(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
         if (wall_clock64() - t0 > 2000000ll) { *abort_flag = 1; break; }
       }
     } else {
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(NT) void k_persistent(float* a, float* b, int nstag
       f32x4 v[FPW / 4 / NT];
 #pragma unroll
       for (int i = 0; i < FPW / 4 / NT; ++i)
-        v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (src * FPW + (threadIdx.x + i * NT) * 4) * 4, 0, AUX));
+        v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (src * FPW + (threadIdx.x + i * NT) * 4) * 4, 0, AUX == 17 ? 16 : AUX));
 #pragma unroll
       for (int i = 0; i < FPW / 4 / NT; ++i) {
         v[i] += 1.0f;
@@ -146,6 +149,9 @@ int main() {
       timed("(b) persistent: L2-local barrier, data through this XCD's L2 (sc0 loads)", [&] {
         hipLaunchKernelGGL((k_persistent<true, 0, 1>), dim3(grid), dim3(NT), 0, st, a, b, NSTAGE, shift, 8, counter, abort_flag, where);
       });
+      timed("(b2) persistent: L2-local barrier, sc1 loads + plain stores", [&] {
+        hipLaunchKernelGGL((k_persistent<true, 0, 17>), dim3(grid), dim3(NT), 0, st, a, b, NSTAGE, shift, 8, counter, abort_flag, where);
+      });
       timed("(c) persistent: agent-scope barrier, data through memory (sc1)", [&] {
         hipLaunchKernelGGL((k_persistent<true, 1, 16>), dim3(grid), dim3(NT), 0, st, a, b, NSTAGE, shift, 8, counter, abort_flag, where);
       });
@@ -157,6 +163,7 @@ int main() {
       hipLaunchKernelGGL((k_persistent<false, 1, 16>), dim3(grid), dim3(NT), 0, st, a, b, NSTAGE, 0, 8, counter, abort_flag, where);
     });
     check(nwg, 8, [&] { hipLaunchKernelGGL((k_persistent<true, 0, 1>), dim3(grid), dim3(NT), 0, st, a, b, NSTAGE, 3, 8, counter, abort_flag, where); });
+    check(nwg, 8, [&] { hipLaunchKernelGGL((k_persistent<true, 0, 17>), dim3(grid), dim3(NT), 0, st, a, b, NSTAGE, 3, 8, counter, abort_flag, where); });
   }
   printf("reference: the same 32 live workgroups spread over all XCDs (stride 1), L2-local protocol (expected to FAIL the data check)\n");
   timed("(b') persistent: L2-local barrier + sc0 data, 32 workgroups on 8 XCDs", [&] {
