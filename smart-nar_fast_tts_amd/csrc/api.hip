@@ -49,6 +49,7 @@ struct ns_model {
   size_t hdr;  // arena header: magic, layout version, arena size, config hash (arena_header below)
   size_t emb, enc_pos, dec_pos, pitch_bins, energy_bins, pitch_emb, energy_emb, mel_w, mel_b;
   size_t pn_in, pn_hid, pn_const;  // derived at ns_finalize_weights: the PostNet over an all-padding utterance (packed rows, forward_mel)
+  size_t pos_long;                 // derived at ns_finalize_weights: the sinusoid table regenerated for POS_LONG_ROWS positions (position_rows)
   std::vector<PostW> post;
   Arena ar;
   float* arena = nullptr;
@@ -74,7 +75,7 @@ static const char* kPredNames[3] = {"duration", "pitch", "energy"};
 // rule or a derived constant in the arena changes), the arena size and a hash of the configuration — so that bytes packed by
 // another build, for another configuration, or never finalized are refused instead of silently misread.
 constexpr uint32_t ARENA_MAGIC = 0x3246534eu;  // "NSF2"
-constexpr uint32_t ARENA_LAYOUT_VERSION = 4;   // round 4: header added (round 3's layout 3 grew the PostNet constants)
+constexpr uint32_t ARENA_LAYOUT_VERSION = 5;   // 5: long position table; 4: header added (round 3's layout 3 grew the PostNet constants)
 constexpr int ARENA_HDR_WORDS = 16;
 static void arena_header(const ns_model* m, uint32_t* w) {
   memset(w, 0, ARENA_HDR_WORDS * sizeof(uint32_t));
@@ -86,6 +87,11 @@ static void arena_header(const ns_model* m, uint32_t* w) {
   w[4] = (uint32_t)(h & 0xffffffffu); w[5] = (uint32_t)(h >> 32);
   w[6] = 1;  // finalized (postnet constants computed)
 }
+// Sequences longer than max_seq_len get a position table regenerated on the fly in the reference (transformer/Models.py:82-87,
+// 218-225: get_sinusoid_encoding_table for the whole length, per call).  The table is a pure function of (position, d), so it is
+// generated ONCE per weight load for this many positions, by the same kernel the per-call path uses (bit-identical), and kept in
+// the arena; only longer sequences still rebuild per call.  Config 2 (T_pad 1010 > 1000) saves a 6.6 us launch per forward.
+constexpr int POS_LONG_ROWS = 8192;
 constexpr int PN_CONST_ROWS = 32;  // synthetic all-padding utterance: rows [10, 22) are deep padding, [22, 32) see the end of the axis
 
 static void expect(ns_model* m, const std::string& name, std::vector<int64_t> shape, bool optional = false) {
@@ -206,6 +212,7 @@ extern "C" int ns_create(const ns_config* cfg, ns_model** out) {
   m->pn_in = m->ar.take((size_t)PN_CONST_ROWS * c.n_mel);
   m->pn_hid = m->ar.take((size_t)2 * PN_CONST_ROWS * c.postnet_dim);
   m->pn_const = m->ar.take((size_t)PN_CONST_ROWS * c.n_mel);
+  m->pos_long = m->ar.take((size_t)POS_LONG_ROWS * c.d_dec);  // (d_enc == d_dec: one table serves both stacks)
   *out = m;
   return 0;
 }
@@ -395,6 +402,7 @@ extern "C" int ns_finalize_weights(ns_model* m, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   NS_HIP(hipMemcpyAsync(m->arena, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, st));
   NS_TRY(postnet_constants(m, st));
+  NS_HIP(launch_sinusoid(POS_LONG_ROWS, c.d_dec, m->arena + m->pos_long, st));
   NS_HIP(hipStreamSynchronize(st));  // img is a local; also makes load_state_dict() synchronous like the reference's
   for (auto& kv : m->staged) { kv.second.data.clear(); kv.second.data.shrink_to_fit(); }
   m->ready = true;
@@ -629,7 +637,9 @@ static int fft_block(ns_model* m, const LayerW& L, int d, int H, const float* x,
 
 // position rows [0,S): cached parameter when S <= max_seq_len, else rebuilt (transformer/Models.py:82-91,218-235)
 static int position_rows(const ns_model* m, size_t cached_off, int S, int d, Scratch& sc, const float** pos, hipStream_t st) {
-  if (S > m->cfg.max_seq_len) {
+  if (S > m->cfg.max_seq_len && S <= POS_LONG_ROWS) {
+    *pos = m->P(m->pos_long);  // rows [0, S) of the regenerated table (its rows do not depend on how many were generated)
+  } else if (S > m->cfg.max_seq_len) {
     NS_HIP(launch_sinusoid(S, d, sc.pos_ext, st));
     *pos = sc.pos_ext;
   } else {

@@ -461,21 +461,37 @@ class FastSpeech2Align:
 
     SPIN_US = builtins.float(os.environ.get("NS_SPIN_US", "300"))  # (builtins.: the class defines a float() method above)  # busy-wait budget for the mid-forward hand-over, then block
 
-    def _wait_phase1(self, dev):
-        """Wait for phase 1 on the launch stream.  A blocking synchronize sleeps and costs ~50 us of wake-up latency per
-        forward (single-utterance p50 1.12 vs 1.07 ms), so spin on an event first — but only for SPIN_US microseconds
-        (phase 1 of one utterance takes ~0.35 ms): a large batch, or many ranks / server threads sharing the host, must not
-        burn a core and hold the GIL for milliseconds.  After the budget the thread blocks in event.synchronize()."""
-        done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream(dev))
+    _UNWRITTEN = int(np.iinfo(np.int64).min)  # what the pinned mel_lens hold until phase 1's last kernel has written them
+    POLL_PINNED = os.environ.get("NS_POLL_PINNED", "1") != "0"  # 0: spin on an event behind the kernel instead (A/B runs)
+
+    def _wait_phase1(self, dev, pin_np=None):
+        """Wait until phase 1 has produced ``mel_lens``.  The kernel that computes them also stores them straight into pinned host
+        memory (one aligned 8-byte store per utterance), so the host polls THAT memory — pre-filled with a sentinel no length can
+        take — instead of an event behind the kernel: the values are visible when the stores land, a few microseconds before the
+        kernel's completion signal (end-of-kernel cache write-back + signal + query).  Everything the GPU does next is ordered by
+        the stream as before; the host only needs the numbers.  A blocking synchronize sleeps and costs ~50 us of wake-up latency
+        per forward (single-utterance p50 1.12 vs 1.07 ms), so the wait spins — but only for SPIN_US microseconds (phase 1 of
+        one utterance takes ~0.35 ms): a large batch, or many ranks / server threads sharing the host, must not burn a core and
+        hold the GIL for milliseconds.  After the budget the thread blocks in event.synchronize()."""
         if self.SPIN_US > 0:
             deadline = time.perf_counter() + self.SPIN_US * 1e-6
-            while not done.query():
-                if time.perf_counter() > deadline:
-                    done.synchronize()
-                    break
-        else:
-            done.synchronize()
+            if pin_np is not None and self.POLL_PINNED:
+                while int(pin_np.min()) == self._UNWRITTEN:
+                    if time.perf_counter() > deadline:
+                        break
+                else:
+                    return
+            else:
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(dev))
+                while not done.query():
+                    if time.perf_counter() > deadline:
+                        break
+                else:
+                    return
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        done.synchronize()
 
     def check_status(self, out=None):
         """``out.check()`` for the given forward output; without an argument, for the most recent forward of this model
@@ -568,7 +584,17 @@ class FastSpeech2Align:
                 o1.append(("e_pred", (B, L), f32))
             blk1 = _OutputBlock(o1, dev)
             ws_enc = self._workspace("enc", self._ws_bytes("enc", B, L, 0), sh)
-            pin, pin_np = self._pinned_lens(B, sh)
+            fixed_T = isinstance(max_mel_len, (int, np.integer)) and not isinstance(max_mel_len, bool)
+            if async_status and not fixed_T:
+                raise ValueError("async_status=True needs max_mel_len=<int>: without a host read the mel axis must be fixed by the caller")
+            if fixed_T and int(max_mel_len) < 0:
+                raise ValueError(f"max_mel_len ({int(max_mel_len)}) is negative")
+            # the pinned host copy of mel_lens: only forwards that READ it on the host hand it to the kernel — a capacity-mode
+            # forward still pending on this stream must not write into the words a later synchronous forward is polling
+            pin = pin_np = None
+            if not (fixed_T and async_status):
+                pin, pin_np = self._pinned_lens(B, sh)
+                pin_np.fill(self._UNWRITTEN)  # (host write, ahead of the enqueue: the hand-over below polls these words)
             tail1 = (B, L, 1.0, float(p_control), float(e_control),
                      _lib.ptr(None if p_frame else target("p_targets", p_targets, (B, L))),
                      _lib.ptr(None if e_frame else target("e_targets", e_targets, (B, L))),
@@ -581,11 +607,6 @@ class FastSpeech2Align:
                 _lib.check(lib.ns_forward_durations(self._h, _lib.ptr(texts_c), _lib.ptr(lens_c), *tail1), "ns_forward_durations")
             blk2 = ws_dec = None
             lens_on_host = False
-            fixed_T = isinstance(max_mel_len, (int, np.integer)) and not isinstance(max_mel_len, bool)
-            if async_status and not fixed_T:
-                raise ValueError("async_status=True needs max_mel_len=<int>: without a host read the mel axis must be fixed by the caller")
-            if fixed_T and int(max_mel_len) < 0:
-                raise ValueError(f"max_mel_len ({int(max_mel_len)}) is negative")
             if fixed_T and async_status:
                 # CAPACITY MODE (model/modules.py:128-131,204-213 `max_len` semantics): the caller fixes the mel axis, so phase 2
                 # is enqueued right behind phase 1 — no event wait, no host read.  What the synchronous path checks on the host
@@ -601,7 +622,7 @@ class FastSpeech2Align:
                     Tc = hint if fixed_T else hint + max(8, hint >> 3)
                     blk2 = _OutputBlock(phase2_outputs(Tc), dev)
                     ws_dec = self._workspace("dec", self._ws_bytes("dec", B, L, Tc), sh)
-                self._wait_phase1(dev)
+                self._wait_phase1(dev, pin_np)
                 lens_on_host = True
                 T = int(pin_np.max())
                 if int(pin_np.min()) < 0:

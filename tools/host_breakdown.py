@@ -18,11 +18,11 @@ def wrap(name):
     return g
 class L2:
     def __getattr__(self, n):
-        return wrap(n) if n in ("ns_forward_durations", "ns_forward_mel", "ns_forward_mel_packed") else getattr(lib, n)
+        return wrap(n) if n in ("ns_forward_durations", "ns_forward_durations_packed", "ns_forward_mel", "ns_forward_mel_packed") else getattr(lib, n)
 m._lib = L2()
 w0 = m._wait_phase1
-def w(dev):
-    t0 = time.perf_counter(); w0(dev); T.setdefault("wait", []).append((t0, time.perf_counter()))
+def w(dev, pin_np=None):
+    t0 = time.perf_counter(); w0(dev, pin_np); T.setdefault("wait", []).append((t0, time.perf_counter()))
 m._wait_phase1 = w
 rows = []
 with torch.no_grad():
