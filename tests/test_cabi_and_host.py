@@ -392,3 +392,23 @@ def test_launch_plan_invariants_and_settled_choices(lib):
     split = {B: lib.ns_plan_attention_split(B, 1010, 2, 128) for B in (9, 12, 16, 17, 20, 24, 32)}
     assert split[16] == 1 and split[32] == 1 and split[9] == 3 and split[17] >= 4 and split[20] == 4 and split[24] == 2, split
     assert lib.ns_plan_attention_split(1, 788, 2, 128) == 16 and lib.ns_plan_attention_split(64, 1041, 8, 64) == 1
+
+
+def test_header_is_plain_c_and_host_entry_points_work_from_c(lib, tmp_path):
+    """include/nar_fs2.h is the drop-in boundary: it must compile as C99 (not only as the C++ the library is written in) and the
+    host-side entry points must work from a plain C program through dlopen — no Python, no torch, no GPU."""
+    import subprocess
+
+    L, _ = lib
+    exe = tmp_path / "host_only"
+    src = os.path.join(ROOT, "tests", "cabi", "host_only.c")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", str(exe), "-ldl"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([str(exe), L.LIB_PATH if hasattr(L, "LIB_PATH") else os.path.join(ROOT, "smart-nar_fast_tts_amd", "csrc", "libnarfs2.so")],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and "C caller ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    # the struct the C side sees is the struct the ctypes binding declares
+    assert f"sizeof(ns_config)={C.sizeof(L.NsConfig)} " in r.stdout

@@ -111,3 +111,48 @@ def test_fuzz_slice_vs_oracle():
     assert big["checked"] >= 2, big
     for r in (small, big):
         assert r["worst"]["mel"] < 1e-3 and r["worst"]["postnet"] < 1e-3, r
+
+
+def test_two_host_threads_each_with_their_own_model():
+    """include/nar_fs2.h THREADING: one ns_model serves one host thread at a time, DIFFERENT models are independent.  Two host
+    threads (ctypes releases the GIL inside the native calls, so the launch sequences really interleave), each with its own
+    model instance on its own HIP stream, 150 forwards each of different batches: every output bit-identical to what the same
+    model gave single-threaded."""
+    import threading
+
+    import smart_nar_fast_tts_amd.workload as wl
+
+    cfg = wl.model_config("ljspeech")
+    sd = wl.synth_state_dict(cfg, seed=0, frames_per_phoneme=8.0)
+    jobs = [(build(cfg, sd), wl.synth_inputs(1, 100, seed=0)), (build(cfg, sd), wl.synth_inputs(3, 40, seed=8, src_lens=[40, 12, 27]))]
+    refs = []
+    for m, inp in jobs:
+        a = [dev(x) for x in inp[:3]]
+        with torch.no_grad():
+            refs.append(m(a[0], a[1], a[2], inp[3]))
+    torch.cuda.synchronize()
+    errors, bad = [], [0, 0]
+
+    def work(k):
+        try:
+            m, inp = jobs[k]
+            st = torch.cuda.Stream()
+            a = [dev(x) for x in inp[:3]]
+            acc = torch.zeros((), dtype=torch.long, device="cuda")
+            with torch.no_grad(), torch.cuda.stream(st):
+                for _ in range(150):
+                    o = m(a[0], a[1], a[2], inp[3])
+                    for j in (0, 1, 2, 3, 4, 5, 9):
+                        acc += (o[j] != refs[k][j]).sum()
+            st.synchronize()
+            bad[k] = int(acc)
+        except Exception as e:  # surfaced below: an exception in a thread must fail the test
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert bad == [0, 0], bad
