@@ -126,6 +126,10 @@ int ns_forward_durations_packed(ns_model* m, const int64_t* texts, const int64_t
                                 float* log_d, float* d_rounded, uint8_t* src_mask, int64_t* mel_lens, float* p_pred, float* e_pred,
                                 int64_t* mel_lens_host, void* stream);
 int64_t ns_last_phase1_rows(const ns_model* m);
+/* Helper for callers whose lengths live on the host: dev[i] = host[i] (int64) on `stream`, the values riding in a kernel's
+ * argument block — one ~3 us launch, no copy command (a pinned-staging async copy of these 128 bytes costs a forward ~35 us of
+ * blit + stream dependency, a pageable copy ~80 us).  host is read before the call returns. */
+int ns_upload_lengths(const int64_t* host, int n, int64_t* dev, void* stream);
 
 /* Phase 2: LengthRegulator + frame-level pitch/energy + MelDecoder + mel_linear + PostNet (+ residual).
  * T is max(mel_lens), or a caller-chosen capacity (max_mel_len, model/modules.py:128-131,204-213 semantics: the mel axis is

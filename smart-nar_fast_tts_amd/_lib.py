@@ -42,6 +42,7 @@ SIGNATURES = {
     "ns_forward_durations": (_I, [_P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ns_forward_durations_packed": (_I, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ns_last_phase1_rows": (C.c_int64, [_P]),
+    "ns_upload_lengths": (_I, [_P, _I, _P, _P]),
     "ns_forward_mel": (_I, [_P, _I, _I, _I, _P, _F, _F, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _P]),
     "ns_forward_mel_packed": (_I, [_P, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _P]),
 

@@ -34,12 +34,16 @@ def collate(data):
     return ids, raw_texts, speakers, pad_1D(texts), text_lens, max(text_lens)
 
 
-def to_device(data, device):
-    """The 6-tuple branch of utils/tools.py:56-63: numpy -> torch on ``device``; ids / raw_texts / max_len pass through."""
+def to_device(data, device, host_lens: bool = False):
+    """The 6-tuple branch of utils/tools.py:56-63: numpy -> torch on ``device``; ids / raw_texts / max_len pass through.
+    EXTENSION ``host_lens``: keep ``src_lens`` as a CPU tensor — forward() accepts it, uploads the values itself (no copy command),
+    may run phase 1 of a ragged batch on packed phoneme rows, and split_outputs reads the lengths without a device-to-host copy."""
     ids, raw_texts, speakers, texts, src_lens, max_src_len = data
     speakers = torch.from_numpy(np.asarray(speakers)).long().to(device)
     texts = torch.from_numpy(np.asarray(texts)).long().to(device)
-    src_lens = torch.from_numpy(np.asarray(src_lens)).to(device)
+    src_lens = torch.from_numpy(np.asarray(src_lens))
+    if not host_lens:
+        src_lens = src_lens.to(device)
     return ids, raw_texts, speakers, texts, src_lens, max_src_len
 
 
@@ -74,18 +78,19 @@ def split_outputs(batch, predictions, preprocess_config):
 
 
 def synthesize(model, batchs, preprocess_config, device="cuda", p_control: float = 1.0, e_control: float = 1.0,
-               streams: int = 1):
+               streams: int = 1, host_lens: bool = False):
     """synthesize.py:59-76 reduced to its tensor contract: to_device -> model(*(batch[2:])) under no_grad ->
     per-utterance results (what synth_samples would plot / vocode).
 
     EXTENSION: ``streams`` > 1 issues consecutive batches round-robin on that many HIP streams and slices the outputs
     after the last one, so the small-grid phase 1 of batch i+1 and the host read between the phases overlap the
     chip-filling phase 2 of batch i (single utterances on one MI355X: +28 % utterances/s with 2 streams).  Results are
-    identical: each forward runs on its own stream with its own scratch."""
+    identical: each forward runs on its own stream with its own scratch.
+    EXTENSION: ``host_lens`` keeps ``src_lens`` on the host (see :func:`to_device`); same results to fp32 summation order."""
     if streams <= 1:
         results = []
         for batch in batchs:
-            batch = to_device(batch, device)
+            batch = to_device(batch, device, host_lens)
             with torch.no_grad():
                 output = model(*(batch[2:]), p_control=p_control, e_control=e_control)
             results.extend(split_outputs(batch, output, preprocess_config))
@@ -97,7 +102,7 @@ def synthesize(model, batchs, preprocess_config, device="cuda", p_control: float
     done = []
     for i, batch in enumerate(batchs):
         with torch.cuda.stream(pool[i % streams]), torch.no_grad():
-            batch = to_device(batch, device)
+            batch = to_device(batch, device, host_lens)
             done.append((batch, model(*(batch[2:]), p_control=p_control, e_control=e_control)))
     torch.cuda.synchronize(dev)
     results = []

@@ -853,6 +853,12 @@ extern "C" int ns_forward_durations(ns_model* m, const int64_t* texts, const int
                            d_rounded, src_mask, mel_lens, p_pred, e_pred, mel_lens_host, stream);
 }
 
+extern "C" int ns_upload_lengths(const int64_t* host, int n, int64_t* dev, void* stream) {
+  if (n < 0 || (n > 0 && (!host || !dev))) return fail("ns_upload_lengths: null argument");
+  NS_HIP(launch_store_lens((const long long*)host, n, (long long*)dev, (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int ns_forward_durations_packed(ns_model* m, const int64_t* texts, const int64_t* src_lens, const int64_t* src_lens_host, int B, int L,
                                            float d_control, float p_control, float e_control, const float* p_targets, const float* e_targets,
                                            void* ws_enc, size_t ws_bytes, float* log_d, float* d_rounded, uint8_t* src_mask,

@@ -152,6 +152,7 @@ hipError_t launch_pack_plan(const long long* mel_lens, int B, int T, int H, int 
 // variance predictors have no mask between their two convolutions (model/modules.py:245-286), so the last valid
 // phoneme reads ONE row past the utterance's end — a row that must be computed, from zeroed encoder output, like the reference does.
 constexpr int PHONEME_GUARD = 2;
+hipError_t launch_store_lens(const long long* host, int n, long long* dst, hipStream_t st);  // dst[i] = host[i], values passed as kernel arguments
 hipError_t launch_pack_plan_only(const long long* lens, int B, int T, int H, int Mp, int* plan, RowMap* rm, hipStream_t st, int guard);
 // (also writes the row maps of *rm: launch_pack_plan_only + this kernel = the whole plan)
 hipError_t launch_embed_pos_packed(const long long* texts, const float* emb, const float* pos, float* out, const RowMap& rm, int B, int Mp, int L,

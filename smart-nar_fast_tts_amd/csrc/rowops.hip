@@ -146,6 +146,24 @@ hipError_t launch_embed_pos(const long long* texts, const float* emb, const floa
   return hipGetLastError();
 }
 
+// Host values -> a device vector WITHOUT a copy command: up to 128 int64 ride in the kernel's argument block (1 KB), the
+// kernel stores them.  A pinned-staging hipMemcpyAsync for 128 bytes costs a forward ~35 us (blit + its stream dependency), a
+// pageable torch .to(device) ~80 us; this is one ~3 us launch at the head of the phase that needs the lengths on the device.
+struct LensBlock { long long v[128]; };
+__global__ void k_store_lens(LensBlock blk, int n, long long* __restrict__ dst) {
+  const int i = threadIdx.x;
+  if (i < n) dst[i] = blk.v[i];
+}
+hipError_t launch_store_lens(const long long* host, int n, long long* dst, hipStream_t st) {
+  for (int o = 0; o < n; o += 128) {
+    LensBlock blk;
+    const int k = n - o < 128 ? n - o : 128;
+    for (int i = 0; i < k; ++i) blk.v[i] = host[o + i];
+    hipLaunchKernelGGL(k_store_lens, dim3(1), dim3(128), 0, st, blk, k, dst + o);
+  }
+  return hipGetLastError();
+}
+
 static void plan_pointers(int* plan, int B, int Mp, RowMap* rm);
 // The same on packed phoneme rows (kernels.h RowMap, api.hip forward_durations): row m is phoneme row_t[m] of utterance row_b[m].
 // Also zeroes the phase's ticket counters (the plan kernels ahead of it do not).

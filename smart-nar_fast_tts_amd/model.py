@@ -442,6 +442,18 @@ class FastSpeech2Align:
         self._ws.move_to_end(key)
         return t[0][:B], t[1][:B]
 
+    def _device_lens(self, B: int, stream_handle) -> torch.Tensor:
+        """A device vector [B] int64 per launch stream for src_lens that arrive on the host, filled by ns_upload_lengths (the values
+        ride in a kernel's argument block: no copy command — a pinned-staging async copy costs a forward ~35 us, a pageable
+        ``.to(device)`` ~80 us)."""
+        key = ("lens", stream_handle)
+        t = self._ws.get(key)
+        if t is None or t.numel() < B:
+            t = torch.empty(max(B, 64), dtype=torch.long, device=self._device)
+            self._ws[key] = t
+        self._ws.move_to_end(key)
+        return t[:B]
+
     def _ws_bytes(self, kind: str, B: int, L: int, T: int) -> int:
         key = (kind, B, L, T)
         n = self._ws_need.get(key)
@@ -542,10 +554,9 @@ class FastSpeech2Align:
             lens_host = np.ascontiguousarray(src_lens.numpy() if torch.is_tensor(src_lens) else np.asarray(src_lens), dtype=np.int64)
             if lens_host.shape != (B,):
                 raise ValueError(f"src_lens must have shape ({B},), got {lens_host.shape}")
-            src_lens_t = torch.from_numpy(lens_host)
+            lens_c = None  # uploaded below, through pinned staging on the launch stream (a pageable .to(device) costs ~80 us)
         else:
-            src_lens_t = src_lens
-        lens_c = src_lens_t.to(device=dev, dtype=torch.long).contiguous()
+            lens_c = src_lens.to(device=dev, dtype=torch.long).contiguous()
         # a phoneme_level feature is predicted on the encoder output ([B,L], model/modules.py:117-126),
         # a frame_level one after the length regulator ([B,T], :139-149)
         p_frame, e_frame = bool(self._cfg.pitch_frame_level), bool(self._cfg.energy_frame_level)
@@ -571,6 +582,9 @@ class FastSpeech2Align:
         with (contextlib.nullcontext() if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)):
             sh = torch.cuda.current_stream(dev).cuda_stream
             st = C.c_void_p(sh)
+            if lens_c is None:
+                lens_c = self._device_lens(B, sh)
+                _lib.check(lib.ns_upload_lengths(C.c_void_p(lens_host.ctypes.data), B, _lib.ptr(lens_c), st), "ns_upload_lengths")
             # Host work is ordered around the GPU's critical path: ONE allocation per phase (the views the caller receives are
             # cut from it after the last launch is enqueued), and everything phase 2 needs that does not depend on T — its
             # output block and scratch at a capacity guessed from the previous forward of this shape — is prepared while

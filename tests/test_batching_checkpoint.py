@@ -121,6 +121,14 @@ def test_stream_pipelined_synthesize_is_identical():
         for a, b in zip(one, many):
             assert a["mel_len"] == b["mel_len"] and torch.equal(a["mel"], b["mel"]), a["basename"]
             assert np.array_equal(a["pitch"], b["pitch"]) and np.array_equal(a["duration"], b["duration"])
+    # src_lens kept on the host (to_device(host_lens=True)): the forward uploads them itself (ns_upload_lengths: kernel arguments,
+    # stream-ordered, so pipelined streams cannot see each other's lengths); batches this small never pack phase 1, so the
+    # results are the one-stream run's, bit for bit
+    for st in (1, 3):
+        host = batching.synthesize(model, batchs, pc, "cuda", streams=st, host_lens=True)
+        for a, b in zip(one, host):
+            assert a["mel_len"] == b["mel_len"] and a["src_len"] == b["src_len"] and torch.equal(a["mel"], b["mel"]), (st, a["basename"])
+            assert np.array_equal(a["duration"], b["duration"])
 
 
 @pytest.mark.gpu
