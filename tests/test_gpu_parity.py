@@ -1037,3 +1037,40 @@ def test_phase1_on_packed_phoneme_rows():
     steps = lambda r: -(-((r + 31) // 32) * 8 // 256)  # noqa: E731
     assert (rows_auto == expect) == (expect * 10 <= 32 * 128 * 9 and steps(expect) < steps(32 * 128)), (rows_auto, expect)
     assert torch.equal(o_pk[5], o_gr[5]) and torch.equal(o_pk[9], o_gr[9])
+
+
+def test_empty_utterance_in_a_batch_end_to_end():
+    """SURVEY.md §8b "Errors": an utterance with src_len == 0 has every attention key masked — an all -inf softmax row, NaN
+    (transformer/Modules.py:19-22) — which FFTBlock's masked_fill then replaces by zeros (transformer/Layers.py:43,46), so it comes out
+    with zero durations and zero frames while its neighbours are untouched.  Through the whole forward, against the oracle: same NaN
+    pattern (none survives in the returned tensors' valid regions), same integers, same values — on the grid, with phase 1 on packed
+    phoneme rows (host src_lens: the empty utterance's window is its two guard rows) and with phase 2 on packed rows."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from oracle import fs2_oracle as orc
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    _MODEL.clear()
+    cfg, sd = weights_for(dict(config="tiny", weight_seed=0, frames_per_phoneme=4.0, dur_weight_scale=0.25))
+    w = orc.to_torch_weights(sd)
+    lens = np.array([20, 0, 7, 13])
+    inp = wl.synth_inputs(4, 20, seed=6, src_lens=np.maximum(lens, 1))
+    texts = inp[1].copy()
+    texts[1, :] = 0   # the empty utterance: all padding tokens
+    with torch.no_grad():
+        ref = orc.forward(w, cfg, torch.from_numpy(inp[0]), torch.from_numpy(texts), torch.from_numpy(lens), inp[3])
+    assert int(ref[9][1]) == 0 and int(ref[9][0]) > 0
+    for mode, pack1 in (("dense", "never"), ("packed", "always")):
+        m = FastSpeech2Align(wl.preprocess_config(), dict(cfg, padded_rows=mode, phase1_packing=pack1)).to("cuda").eval()
+        m.load_state_dict(sd)
+        for lens_arg in (dev(lens), torch.from_numpy(lens.copy())):
+            with torch.no_grad():
+                out = m(dev(inp[0]), dev(texts), lens_arg, inp[3], p_targets=ref[2].cuda(), e_targets=ref[3].cuda())
+            torch.cuda.synchronize()
+            what = f"{mode}, src_lens on the {'device' if lens_arg.is_cuda else 'host'}"
+            assert np.array_equal(out[5].cpu().numpy(), ref[5].numpy()) and np.array_equal(out[9].cpu().numpy(), ref[9].numpy()), what
+            assert np.array_equal(out[6].cpu().numpy(), ref[6].numpy()) and np.array_equal(out[7].cpu().numpy(), ref[7].numpy()), what
+            for i in (0, 1, 3, 4):
+                g, r = out[i].cpu(), ref[i]
+                assert torch.equal(torch.isnan(g), torch.isnan(r)), (what, NAMES[i], int(torch.isnan(g).sum()), int(torch.isnan(r).sum()))
+                ok = ~torch.isnan(r)
+                assert float((g[ok] - r[ok]).abs().max()) < 2e-5, (what, NAMES[i])
