@@ -789,7 +789,7 @@ static int forward_durations(ns_model* m, const int64_t* texts, const int64_t* s
   bool packed = lens_host && !m->enc.empty() && launch_planner_enabled() && c.pitch_frame_level && c.energy_frame_level && c.phase1_packing != 2;
   if (packed) {
     // Phase-1 launches are small grids: their time is steps of 256 workgroups x a K loop, not rows (measured, config-2 shape with
-    // 0.66 of the rows: 4.27 ms packed vs 4.22 ms on the grid — the same two steps everywhere, plus the plan / unpack / attention-merge
+    // 0.66 of the rows: 4.32 ms packed vs 4.29 ms on the grid — the same two steps everywhere, plus the plan / unpack / attention-merge
     // launches).  So pack only when the rows drop by a whole step of the launch that dominates the phase, the FFN k=9 GEMM on
     // 32x128 tiles (4 x ~38 us per step saved against ~50 us of extra launches), and by at least 10 %.
     Mp = phase1_packed_rows(lens_host, B, L);
