@@ -392,8 +392,8 @@ def main():
     # ---- sustained leg: the same forward back to back for ~10 s (or 2000 steps).  Every headline figure above is a 0.1 s burst;
     # this is what the chip holds once clocks and temperatures have settled.  Per-step times from one event per step on the
     # launch stream; the dominant kernel is timed (dispatch events) during the first and the last 200 steps only.
-    sustained = None
-    if args.sustained_s > 0 and not args.no_extras and streams is None:
+    sustained_error = None
+    def run_sustained():
         est = elapsed_max / args.steps
         n_sus = int(max(50, min(2000, -(-args.sustained_s // est))))
         edge = min(200, n_sus // 4)
@@ -423,7 +423,7 @@ def main():
         sus_max = float(sstat[0])
         quarter = max(1, n_sus // 4)
         order = [ev[i].elapsed_time(ev[i + 1]) for i in range(n_sus)]
-        sustained = {"steps": n_sus, "seconds": round(sus_max, 3), "ms_per_step": sus_max / n_sus * 1e3,
+        return {"steps": n_sus, "seconds": round(sus_max, 3), "ms_per_step": sus_max / n_sus * 1e3,
                      "value": frames_total * n_sus / sus_max, "unit": "frames/s",
                      "step_ms": {"p50": round(sms[n_sus // 2], 3), "p99": round(sms[min(n_sus - 1, int(n_sus * 0.99))], 3),
                                  "min": round(sms[0], 3), "max": round(sms[-1], 3),
@@ -434,6 +434,17 @@ def main():
                      "clock": clk.summary(),
                      "note": "rank 0's shard for the per-step and per-kernel figures; value = whole job over the slowest rank"}
 
+
+    sustained = None
+    if args.sustained_s > 0 and not args.no_extras and streams is None:
+        if dist is None:
+            try:  # (single process: a failure of this secondary leg must not cost the run its headline line)
+                sustained = run_sustained()
+            except Exception as e:  # noqa: BLE001
+                sustained = None
+                sustained_error = repr(e)[:300]
+        else:     # (N > 1: the leg contains collectives — an exception on one rank must stop the job, not leave the others waiting)
+            sustained = run_sustained()
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -493,6 +504,8 @@ def main():
                      "share_of_step_time": round((k_ms / len(range(0, args.steps, PROF_EVERY))) / (elapsed / args.steps * 1e3) if elapsed > 0 else 0.0, 3),
                      "geometry": geom},
     }
+    if sustained_error:
+        res["sustained"] = {"error": sustained_error}
     if sustained:
         res["sustained"] = sustained
         res["burst"] = {"value": value, "ms_per_step": res["ms_per_step"], "steps": args.steps}

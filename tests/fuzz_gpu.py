@@ -75,8 +75,17 @@ def run(args, max_seconds=None):
         # src_lens on the host (every other case): phase 1 then runs on packed phoneme rows where that pays (nar_fs2.h)
         lens_arg = ti[2] if it % 2 else dev(inp[2])
         with torch.no_grad():
-            ref = orc.forward(w, cfg, ti[0], ti[1], ti[2], inp[3], **okw)
             out = m(dev(inp[0]), dev(inp[1]), lens_arg, inp[3], **kw)
+            try:
+                ref = orc.forward(w, cfg, ti[0], ti[1], ti[2], inp[3], **okw)
+            except RuntimeError as e:
+                # every duration rounds to zero: T = 0, and torch's Conv1d refuses an empty axis ("Kernel size can't be greater than
+                # actual input size") in the predictors — the reference raises here too; this path returns [B, 0, .] outputs instead
+                if "Kernel size" not in str(e):
+                    raise
+                assert int(out[9].max()) == 0 and out[0].shape[1] == 0, (tag, "the oracle refused an empty mel axis but the HIP path produced frames")
+                skipped += 1
+                continue
         e = float((out[4].cpu() - ref[4]).abs().max())
         worst["log_d"] = max(worst["log_d"], e)
         assert e < 1e-4, (tag, "log_d", e)
