@@ -897,7 +897,9 @@ def test_packed_rows_match_the_dense_grid_on_ragged_batches():
             worst[NAMES[i]] = float((packed[i] - dense[i]).abs().max())
             assert torch.isfinite(packed[i]).all()
         print("packed vs dense", cfg_name, extra, "fpp", fpp, "rows", rows_packed, "of", rows_dense, worst)
-        assert worst["output"] < 2e-5 and worst["postnet_output"] < 2e-5 and worst["e_predictions"] < 2e-4, worst
+        # (the packed path must not hide behind the bucket-edge bound — same arithmetic per row, so it agrees with the
+        #  grid to fp32 summation order: measured worst 2.4e-6 on mel / PostNet mel over these six batches, bound 5e-6)
+        assert worst["output"] < 5e-6 and worst["postnet_output"] < 5e-6 and worst["e_predictions"] < 2e-4, worst
         # with targets the prediction itself is returned: pitch does not depend on the targets, energy on the pitch bucket only
         assert worst["p_predictions"] < 2e-3 * max(1.0, float(dense[2].abs().max())), worst
         # free-running: the packed run takes its own bucket decisions; frame counts and masks still agree, values stay finite
