@@ -111,11 +111,34 @@ def synthesize(model, batchs, preprocess_config, device="cuda", p_control: float
     return results
 
 
-def bucket_by_length(lengths, max_batch: int, max_pad_fraction: float = 0.1):
+# Batch sizes at which a forward of ~1000-frame utterances sits at the top of a step of the chip (every large launch fills its last
+# round of 256 workgroups): the local minima of ms per utterance in profiles/r04_batch_size_sweep.txt — 4: 0.435, 8: 0.361,
+# 12: 0.366, 16: 0.327, 24: 0.330, 32: 0.314 ms — where 9 costs 0.429 and 17 0.379 (what is left of the
+# staircase is granularity one summation order per forward cannot buy back; the batch composition CAN avoid it).
+STEP_FRIENDLY_SIZES = (1, 2, 4, 8, 12, 16, 24, 32)
+
+
+def step_friendly_sizes(n: int, max_batch: int, sizes=STEP_FRIENDLY_SIZES):
+    """EXTENSION: cut ``n`` utterances into batch sizes from ``sizes`` (largest first, each <= max_batch): 9 -> [8, 1],
+    17 -> [16, 1], 20 -> [16, 4], 33 -> [32, 1].  Each batch is then one exact forward of the reference's semantics on that
+    batch; which utterances share a batch is the caller's choice in the reference too (dataset.py:182-191)."""
+    if n < 0 or max_batch < 1:
+        raise ValueError("n >= 0 and max_batch >= 1")
+    allowed = sorted({s for s in sizes if 1 <= s <= max_batch} | {1}, reverse=True)
+    out = []
+    while n > 0:
+        s = next(a for a in allowed if a <= n)
+        out.append(s)
+        n -= s
+    return out
+
+
+def bucket_by_length(lengths, max_batch: int, max_pad_fraction: float = 0.1, step_friendly: bool = False):
     """EXTENSION (not in the reference): group utterance indices into batches of similar length.
 
     Sorted by length, a batch is closed when it holds ``max_batch`` items or when admitting the next item would make
-    the shortest member's padding exceed ``max_pad_fraction`` of the batch's max length.  Every index appears once."""
+    the shortest member's padding exceed ``max_pad_fraction`` of the batch's max length.  Every index appears once.
+    ``step_friendly``: every such group is further cut into the batch sizes of :func:`step_friendly_sizes`."""
     order = np.argsort(np.asarray(lengths), kind="stable")[::-1]
     batches, cur = [], []
     for idx in order:
@@ -127,4 +150,12 @@ def bucket_by_length(lengths, max_batch: int, max_pad_fraction: float = 0.1):
         cur.append(int(idx))
     if cur:
         batches.append(cur)
+    if step_friendly:
+        cut = []
+        for b in batches:
+            o = 0
+            for s in step_friendly_sizes(len(b), max_batch):
+                cut.append(b[o:o + s])
+                o += s
+        batches = cut
     return batches

@@ -43,6 +43,17 @@ def test_bucket_by_length_partitions():
             longest = max(lens[i] for i in g)
             assert all(longest - lens[i] <= frac * longest for i in g)
     assert len(bucket_by_length(lens, 128, 1.0)) == 1
+    # step-friendly cutting: batch sizes that sit at the top of a step of the chip (profiles/r04_batch_size_sweep.txt), same partition property
+    from smart_nar_fast_tts_amd.batching import STEP_FRIENDLY_SIZES, step_friendly_sizes
+
+    assert step_friendly_sizes(9, 16) == [8, 1] and step_friendly_sizes(17, 32) == [16, 1] and step_friendly_sizes(20, 16) == [16, 4]
+    assert step_friendly_sizes(33, 32) == [32, 1] and step_friendly_sizes(0, 8) == [] and step_friendly_sizes(7, 3) == [2, 2, 2, 1]
+    for n in range(0, 70):
+        for mb in (1, 3, 8, 16, 32):
+            c = step_friendly_sizes(n, mb)
+            assert sum(c) == n and all(1 <= x <= mb and (x in STEP_FRIENDLY_SIZES) for x in c) and c == sorted(c, reverse=True)
+    b = bucket_by_length(lens, 16, 1.0, step_friendly=True)
+    assert sorted(i for g in b for i in g) == list(range(len(lens))) and all(len(g) in STEP_FRIENDLY_SIZES for g in b)
 
 
 def test_inference_state_dict_filters_training_state():
