@@ -597,6 +597,26 @@ def main():
                                             "p50_ms": round(float(np.median(latc)), 3), "min_ms": round(min(latc), 3),
                                             "max_ms": round(max(latc), 3), "n": len(latc), "status": oc.check(),
                                             "bit_identical_to_sync_path": bool(torch.equal(oc[1], o1[1]) and torch.equal(oc[9], o1[9]))}
+            # independent B=1 requests on several HIP streams of the one model: a B=1 forward is ~80 launches of fewer than 256
+            # workgroups, and two queues overlap whenever both launches' workgroups fit on the chip (tools/lab/two_queues.hip)
+            conc = {}
+            with torch.no_grad():
+                for ns in (1, 4):
+                    sts = [torch.cuda.Stream(dev) for _ in range(ns)]
+                    n_req = 200
+                    for i in range(2 * ns + n_req):
+                        if i == 2 * ns:
+                            torch.cuda.synchronize()
+                            t0 = time.perf_counter()
+                        with torch.cuda.stream(sts[i % ns]):
+                            ocs = model(a1[0], a1[1], a1[2], L1, max_mel_len=cap, async_status=True)
+                    torch.cuda.synchronize()
+                    conc[ns] = n_req / (time.perf_counter() - t0)
+                    same = bool(torch.equal(ocs[1], o1[1]))
+            res["latency_capacity_mode"]["concurrent_streams"] = {
+                "utterances_per_s": {str(k): round(v, 1) for k, v in conc.items()}, "speedup_4_streams": round(conc[4] / conc[1], 3),
+                "bit_identical_to_sync_path": same,
+                "note": "200 B=1 forwards round-robin over 1 and 4 streams, one host thread; tools/multi_stream_small.py has B=1,2,4 x 1..8 streams"}
 
     if args.gpus == 1 and not args.no_extras and not b3:
         # Variable-length batches (BASELINE.json config 5: "variable-length masking stress"): the same model on a RAGGED batch of
