@@ -78,7 +78,7 @@ def split_outputs(batch, predictions, preprocess_config):
 
 
 def synthesize(model, batchs, preprocess_config, device="cuda", p_control: float = 1.0, e_control: float = 1.0,
-               streams: int = 1, host_lens: bool = False):
+               streams: int = 1, host_lens: bool = False, max_mel_len=None):
     """synthesize.py:59-76 reduced to its tensor contract: to_device -> model(*(batch[2:])) under no_grad ->
     per-utterance results (what synth_samples would plot / vocode).
 
@@ -86,7 +86,16 @@ def synthesize(model, batchs, preprocess_config, device="cuda", p_control: float
     after the last one, so the small-grid phase 1 of batch i+1 and the host read between the phases overlap the
     chip-filling phase 2 of batch i (single utterances on one MI355X: +28 % utterances/s with 2 streams).  Results are
     identical: each forward runs on its own stream with its own scratch.
-    EXTENSION: ``host_lens`` keeps ``src_lens`` on the host (see :func:`to_device`); same results to fp32 summation order."""
+    EXTENSION: ``host_lens`` keeps ``src_lens`` on the host (see :func:`to_device`); same results to fp32 summation order.
+    EXTENSION: ``max_mel_len`` (an int; with ``streams`` > 1) fixes every forward's mel axis (model/modules.py:128-131 ``max_len``
+    semantics) so that no forward waits on the host between its phases: the forwards of different streams then overlap
+    freely (single utterances: 1.9x utterances/s on 4 streams, profiles/r04_multi_stream_small.txt).  Each batch's result is the
+    reference's with ``max_len = max_mel_len``: a batch's longest utterance gains padding, which changes ITS output in the
+    reference too (the variance predictors are unmasked between their convolutions) — pass the exact length
+    for single utterances whose un-padded result is wanted.  An utterance longer than ``max_mel_len`` raises ValueError once
+    the batches are done — it is never silently cut."""
+    if max_mel_len is not None and streams <= 1:
+        raise ValueError("max_mel_len is the capacity of the multi-stream mode; pass streams > 1 with it")
     if streams <= 1:
         results = []
         for batch in batchs:
@@ -103,10 +112,16 @@ def synthesize(model, batchs, preprocess_config, device="cuda", p_control: float
     for i, batch in enumerate(batchs):
         with torch.cuda.stream(pool[i % streams]), torch.no_grad():
             batch = to_device(batch, device, host_lens)
-            done.append((batch, model(*(batch[2:]), p_control=p_control, e_control=e_control)))
+            if max_mel_len is None:
+                output = model(*(batch[2:]), p_control=p_control, e_control=e_control)
+            else:
+                output = model(*(batch[2:]), max_mel_len=int(max_mel_len), async_status=True, p_control=p_control, e_control=e_control)
+            done.append((batch, output))
     torch.cuda.synchronize(dev)
     results = []
     for batch, output in done:
+        if max_mel_len is not None:
+            output.check()
         results.extend(split_outputs(batch, output, preprocess_config))
     return results
 

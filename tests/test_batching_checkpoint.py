@@ -140,6 +140,35 @@ def test_stream_pipelined_synthesize_is_identical():
         for a, b in zip(one, host):
             assert a["mel_len"] == b["mel_len"] and a["src_len"] == b["src_len"] and torch.equal(a["mel"], b["mel"]), (st, a["basename"])
             assert np.array_equal(a["duration"], b["duration"])
+    # capacity mode on the streams (max_mel_len): no host wait inside a forward; every batch runs as the reference would with
+    # max_len = max_mel_len (model/modules.py:128-131).  That is bit-identical to the synchronous global-pad forward on the grid;
+    # against the un-padded run only utterances that already had >= 10 frames of padding are comparable — a batch's longest utterance GAINS
+    # padding, which changes its output in the reference too.
+    cap = max(r["mel_len"] for r in one) + 7
+    capd = batching.synthesize(model, batchs, pc, "cuda", streams=4, max_mel_len=cap)
+    model.packed_rows = False
+    try:
+        padded = []
+        for batch in batchs:
+            bd = batching.to_device(batch, "cuda")
+            with torch.no_grad():
+                padded.extend(batching.split_outputs(bd, model(*(bd[2:]), max_mel_len=lambda t: cap), pc))
+    finally:
+        model.packed_rows = True
+    # (and one within the PostNet's reach of its batch's old padded end — 5 layers x 2 frames — saw the grid's zero edge there)
+    t_pad = [max(one[j - j % 2]["mel_len"], one[j - j % 2 + 1]["mel_len"]) for j in range(40)]
+    n_cmp = 0
+    for j, (a, g, b) in enumerate(zip(one, padded, capd)):
+        assert a["mel_len"] == b["mel_len"] and np.array_equal(a["duration"], b["duration"]), a["basename"]
+        assert torch.equal(g["mel"], b["mel"]) and np.array_equal(g["pitch"], b["pitch"]), a["basename"]
+        if a["mel_len"] + 10 <= t_pad[j]:
+            n_cmp += 1
+            assert float((a["mel"] - b["mel"]).abs().max()) <= 2e-5, a["basename"]
+    assert n_cmp >= 10
+    with pytest.raises(ValueError, match="cut off"):
+        batching.synthesize(model, batchs, pc, "cuda", streams=2, max_mel_len=max(r["mel_len"] for r in one) - 1)
+    with pytest.raises(ValueError, match="streams"):
+        batching.synthesize(model, batchs, pc, "cuda", max_mel_len=cap)
 
 
 @pytest.mark.gpu
