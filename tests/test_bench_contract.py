@@ -51,6 +51,8 @@ def test_bench_json_contract():
     # both latency figures of config 1: the synchronous forward (the headline p50) and capacity mode beside it
     lat, cap = d["latency"], d["latency_capacity_mode"]
     assert lat["p50_ms"] > 0 and cap["p50_ms"] > 0 and cap["bit_identical_to_sync_path"] is True and cap["status"] == [0]
+    pc_ = d["pipelined"]["capacity_mode"]  # two streams in capacity mode: same kernels, same bits, not the headline
+    assert pc_["bit_identical_to_sync_path"] is True and pc_["value"] > 0.9 * d["value"]
     cs = cap["concurrent_streams"]  # independent B=1 requests overlap across streams, and stay bit-identical
     assert cs["bit_identical_to_sync_path"] is True and cs["utterances_per_s"]["4"] > cs["utterances_per_s"]["1"] > 0
     assert [x["rank"] for x in d["per_rank"]] == [0] and d["per_rank"][0]["valid_frames"] == d["config"]["valid_frames_per_step"]
