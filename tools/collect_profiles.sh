@@ -64,5 +64,9 @@ rocprofv3 --kernel-trace --stats --output-format rocpd csv -d "$OUT/${R}_trace_b
 # the long randomized parity run (the -m gpu suite holds a time-boxed slice of it: tests/test_gpu_stress.py)
 python "$ROOT/tests/fuzz_gpu.py" --iters 360 --seed 41 > "$OUT/${R}_fuzz.txt" 2>&1
 python "$ROOT/tests/fuzz_gpu.py" --iters 40 --seed 42 --big >> "$OUT/${R}_fuzz.txt" 2>&1
+# forwards in flight on several streams (capacity mode): independent B=1 requests, and the batch-size staircase as throughput
+# (the committed profiles/rNN_multi_stream_*.txt are these outputs plus a "Reading:" paragraph)
+python "$ROOT/tools/multi_stream_small.py" > "$OUT/${R}_multi_stream_small.raw.txt" 2>&1
+python "$ROOT/tools/multi_stream_small.py" --batches 8,9,12,16,17,20 --phonemes 128 --streams 1,2,3 --n 100 > "$OUT/${R}_multi_stream_batches.raw.txt" 2>&1
 ls -d "$OUT"/${R}_*/ | head -40
 cat "$OUT/${R}_bench.json" | cut -c1-300
