@@ -89,7 +89,7 @@ def synthesize(model, batchs, preprocess_config, device="cuda", p_control: float
     EXTENSION: ``host_lens`` keeps ``src_lens`` on the host (see :func:`to_device`); same results to fp32 summation order.
     EXTENSION: ``max_mel_len`` (an int; with ``streams`` > 1) fixes every forward's mel axis (model/modules.py:128-131 ``max_len``
     semantics) so that no forward waits on the host between its phases: the forwards of different streams then overlap
-    freely (single utterances: 1.9x utterances/s on 4 streams, profiles/r04_multi_stream_small.txt).  Each batch's result is the
+    freely (single utterances: 1.9x utterances/s on 8 streams, profiles/r04_multi_stream_small.txt).  Each batch's result is the
     reference's with ``max_len = max_mel_len``: a batch's longest utterance gains padding, which changes ITS output in the
     reference too (the variance predictors are unmasked between their convolutions) — pass the exact length
     for single utterances whose un-padded result is wanted.  An utterance longer than ``max_mel_len`` raises ValueError once

@@ -412,7 +412,7 @@ class FastSpeech2Align:
         return ms.value, fl.value, n.value
 
     # ---- forward -------------------------------------------------------------------------------
-    MAX_WORKSPACE_STREAMS = 4  # scratch sets kept alive (each is an enc + dec pair; config 2: ~230 MB per stream)
+    MAX_WORKSPACE_STREAMS = 8  # streams whose scratch set is kept alive (enc + dec + length buffers; config 2: ~230 MB per stream)
 
     def _workspace(self, key: str, nbytes: int, stream_handle=None) -> torch.Tensor:
         # one scratch set per (kind, stream): forwards issued on different streams may run concurrently on the GPU
@@ -425,9 +425,19 @@ class FastSpeech2Align:
             w = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self._device)
             self._ws[key] = w
         self._ws.move_to_end(key)
-        while len(self._ws) > 3 * self.MAX_WORKSPACE_STREAMS:
-            self._ws.popitem(last=False)
+        self._evict_streams(self._ws, self.MAX_WORKSPACE_STREAMS)
         return w
+
+    @staticmethod
+    def _evict_streams(ws, max_streams: int) -> None:
+        """Bound the scratch cache by STREAMS, not entries: while more than ``max_streams`` distinct stream handles hold
+        entries, the whole set (enc, dec, pinned and device lengths) of the stream whose most recent use is oldest goes."""
+        last_use = {}
+        for i, k in enumerate(ws):  # least recently used first
+            last_use[k[1]] = i
+        for old in sorted(last_use, key=last_use.get)[:max(0, len(last_use) - max_streams)]:
+            for k in [k for k in ws if k[1] == old]:
+                del ws[k]
 
     def _pinned_lens(self, B: int, stream_handle=None):
         """[B] int64 in pinned (device-visible) host memory, one buffer per launch stream: phase 1's last kernel writes

@@ -245,14 +245,28 @@ def test_workspace_cache_is_bounded():
 
     from smart_nar_fast_tts_amd.model import FastSpeech2Align
 
-    cap = 3 * FastSpeech2Align.MAX_WORKSPACE_STREAMS  # enc + dec scratch + the pinned mel_lens buffer per stream
+    cap = FastSpeech2Align.MAX_WORKSPACE_STREAMS
     ws = OrderedDict()
-    for i in range(50):  # what _workspace does per call, without a device
-        ws[("enc", i)] = i
-        ws.move_to_end(("enc", i))
-        while len(ws) > cap:
-            ws.popitem(last=False)
-    assert len(ws) == cap and ("enc", 49) in ws and ("enc", 0) not in ws
+    for i in range(50):  # what a forward on a fresh stream does per call, without a device: four entries per stream
+        for kind in ("enc", "pin", "lens", "dec"):
+            ws[(kind, i)] = i
+            ws.move_to_end((kind, i))
+            FastSpeech2Align._evict_streams(ws, cap)
+    assert len(ws) == 4 * cap and {k[1] for k in ws} == set(range(50 - cap, 50))
+    # round-robin over as many streams as the bound keeps: nothing is ever evicted (the stream pool of batching.synthesize)
+    ws = OrderedDict()
+    for i in range(5 * cap):
+        for kind in ("enc", "pin", "lens", "dec"):
+            ws[(kind, i % cap)] = ws.get((kind, i % cap), i)
+            ws.move_to_end((kind, i % cap))
+            FastSpeech2Align._evict_streams(ws, cap)
+    assert len(ws) == 4 * cap and all(v < cap for v in ws.values())
+    # a stream is judged by its MOST RECENT use: touching one entry of the oldest stream keeps its whole set
+    ws = OrderedDict(((kind, st), 0) for st in range(cap) for kind in ("enc", "dec"))
+    ws.move_to_end(("enc", 0))
+    ws[("enc", cap)] = 0
+    FastSpeech2Align._evict_streams(ws, cap)
+    assert ("dec", 0) in ws and ("enc", 1) not in ws and ("dec", 1) not in ws
 
 
 def test_default_init_state_dict_follows_torch_initialisers():
