@@ -409,7 +409,21 @@ def main():
     # launch stream; the dominant kernel is timed (dispatch events) during the first and the last 200 steps only.
     sustained_error = None
     def run_sustained():
-        est = elapsed_max / args.steps
+        # how many steps fill the leg: from 10 calibration steps run now, behind 20 more untimed ones (the K-step burst of a cold process — the driver's first
+        # command on a fresh box, `--steps 3` in the contract test — can be twice as slow as the steady state, and a count planned
+        # from it ends the leg after half the time asked for); every rank must loop the same count (global-pad steps hold a collective)
+        with torch.no_grad():
+            for _ in range(20):  # (the clock settles within the first forwards of a process)
+                step()
+            fence()
+            t0c = time.perf_counter()
+            for _ in range(10):
+                step()
+            fence()
+        est_t = torch.tensor([min(elapsed_max / args.steps, (time.perf_counter() - t0c) / 10)], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(est_t, op=dist.ReduceOp.MIN)
+        est = float(est_t[0])
         n_sus = int(max(50, min(2000, -(-args.sustained_s // est))))
         edge = min(200, n_sus // 4)
         with torch.no_grad(), ClockSampler(dev_index) as clk:
