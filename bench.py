@@ -179,6 +179,74 @@ class ClockSampler:
                 "samples": len(self.samples), "sclk_mhz": stat("sclk_mhz"), "gpu_busy_pct": stat("busy_pct"), "power_w": stat("power_w")}
 
 
+def run_other_config(name, dev, model=None, sd=None, steps=5, warmup=3, oracle_slice=8, check=True):
+    """One BASELINE config other than the headline workload, on the driver's clock: `steps` forwards after `warmup`, the dominant
+    kernel (decoder FFN w_1) from the dispatch events of two further forwards, and the oracle beside it on a slice of at most
+    `oracle_slice` utterances of the same batch (the full oracle at B = 64 takes minutes): durations / frame counts identical,
+    PostNet mel with the bucket decisions pinned.  `model` / `sd`: reuse the headline model when the weights are the same."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    cfg_name, B, L, fpp = wl.WORKLOADS[name]
+    cfg = wl.model_config(cfg_name)
+    t_a = time.perf_counter()
+    if model is None:
+        sd = wl.synth_state_dict(cfg, seed=0, frames_per_phoneme=fpp) if sd is None else sd
+        model = FastSpeech2Align(wl.preprocess_config(), cfg).to(dev).eval()
+        model.load_state_dict(sd)
+    sp, tx, ln, Lmax = wl.synth_inputs(B, L, seed=0)
+    a = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (sp, tx, ln)]
+    with torch.no_grad():
+        for _ in range(warmup):
+            out = model(a[0], a[1], a[2], Lmax)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = model(a[0], a[1], a[2], Lmax)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        model.profile_slots((0,))
+        for _ in range(2):
+            model(a[0], a[1], a[2], Lmax)
+        torch.cuda.synchronize()
+        k_ms, k_flops, k_n = model.read_profile(0)
+        model.profile_slots(())
+    frames, T_pad = int(out[9].sum()), int(out[0].shape[1])
+    flops_frame = wl.algorithmic_flops_per_frame(cfg, T_pad, L, fpp)
+    tf = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
+    res = {"workload": f"{name}: batch {B}, phoneme_len {L}, T_pad {T_pad}, d_model {cfg['transformer']['decoder_hidden']}, "
+                       f"{cfg['transformer']['encoder_layer']}+{cfg['transformer']['decoder_layer']} FFT layers, "
+                       f"length regulator {cfg.get('length_regulator', 'hard')}",
+           "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 4), "value": round(frames / dt, 1), "unit": "frames/s",
+           "T_pad": T_pad, "valid_frames": frames, "rows_phase2": int(model._lib.ns_last_phase2_rows(model._h)),
+           "end_to_end_frac_mfma_peak": round(flops_frame * frames / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+           "dominant_kernel": {"kernel": "k_conv_gemm (decoder FFN w_1)", "achieved_tflops": round(tf, 2), "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+                               "launches": int(k_n), "avg_launch_ms": round(k_ms / max(k_n, 1), 4),
+                               "timed": "HIP events on the dispatch packets of two forwards after the timed steps"}}
+    if check:
+        from oracle import fs2_oracle as orc
+
+        Bs = min(B, oracle_slice)
+        w = orc.to_torch_weights(sd)
+        ci = [torch.from_numpy(np.ascontiguousarray(x[:Bs])) for x in (sp, tx, ln)]
+        lr = cfg.get("length_regulator", "hard")
+        with torch.no_grad():
+            ref = orc.forward(w, cfg, ci[0], ci[1], ci[2], Lmax, length_regulator=lr)
+            o = model(a[0][:Bs], a[1][:Bs], a[2][:Bs], Lmax)
+            pin = model(a[0][:Bs], a[1][:Bs], a[2][:Bs], Lmax, p_targets=ref[2].to(dev), e_targets=ref[3].to(dev))
+        valid = ~ref[7].numpy()
+        same_shape = tuple(pin[1].shape) == tuple(ref[1].shape)
+        diff = (pin[1].cpu() - ref[1]).abs() if same_shape else None
+        res["check_vs_oracle"] = {
+            "slice": f"the first {Bs} of the {B} utterances, as a batch of their own (both sides)",
+            "durations_equal": bool(torch.equal(o[5].cpu(), ref[5])), "frame_counts_equal": bool(torch.equal(o[9].cpu(), ref[9])),
+            "valid_frames": int(valid.sum()),
+            "postnet_max_abs_buckets_pinned": None if diff is None else float(diff.max()),
+            "frames_over_1e-3_buckets_pinned": None if diff is None else int(((diff.amax(dim=2) > 1e-3).numpy() & valid).sum())}
+    res["leg_seconds"] = round(time.perf_counter() - t_a, 2)
+    return res, model, sd
+
+
 def self_launch(n_gpus: int) -> int:
     """`python bench.py --gpus N` without a launcher: run the same command line as N ranks under torch.distributed.run
     (one process per GPU, rendezvous on 127.0.0.1) and hand its output and exit code through."""
@@ -209,6 +277,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override the workload's per-GPU batch size (sweeps; not a BASELINE config)")
     ap.add_argument("--streams", type=int, default=1, help="issue consecutive steps round-robin on this many HIP streams")
     ap.add_argument("--global-pad", action="store_true", help="pad every shard to the global max mel length (all-reduce MAX)")
+    ap.add_argument("--balance", choices=["count", "phonemes"], default=None,
+                    help="how the global batch is split over the ranks (sharding.shard_indices): contiguous, or longest-first on the "
+                         "phoneme counts; default: contiguous for the uniform BASELINE batch, phonemes with --ragged")
     ap.add_argument("--sustained-s", type=float, default=10.0,
                     help="sustained leg after the timed region: back-to-back forwards for this many seconds or 2000 steps, whichever "
                          "comes first (0 = off; skipped with --no-extras)")
@@ -289,7 +360,9 @@ def main():
         ragged = rr.randint(max(1, L // 8), L + 1, size=B_shard * world)
         ragged[::B_shard] = L
     sp, tx, ln, _ = wl.synth_inputs(B_shard * world, L, seed=0, src_lens=ragged)
-    sp, tx, ln, Lmax = sharding.shard_batch(sp, tx, ln, world, rank)
+    balance = args.balance or ("phonemes" if args.ragged else "count")
+    shard_phonemes = [int(np.asarray(ln)[p].sum()) for p in sharding.shard_indices(ln, world, balance)]
+    sp, tx, ln, Lmax = sharding.shard_batch(sp, tx, ln, world, rank, balance=balance)
     speakers, texts, src_lens = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (sp, tx, ln))
     pad_fn = sharding.global_max if (args.global_pad and world > 1) else None
 
@@ -506,13 +579,18 @@ def main():
         "devices": devices, "backend": backend, "world_size_seen_by_rccl": world_seen, "one_gpu_rig": one_gpu, "per_rank": per_rank,
         "init": dict(weights_info, init_s=round(t_ready - t_init0, 3)),
         "rank_spread": {"ms_per_step_max": max(r["ms_per_step"] for r in per_rank), "ms_per_step_min": min(r["ms_per_step"] for r in per_rank),
-                        "max_over_min": round(max(r["ms_per_step"] for r in per_rank) / max(min(r["ms_per_step"] for r in per_rank), 1e-9), 4)},
+                        "max_over_min": round(max(r["ms_per_step"] for r in per_rank) / max(min(r["ms_per_step"] for r in per_rank), 1e-9), 4),
+                        # what the split gave every rank to do (sharding.shard_indices): phonemes on the host side, rows of phase 2
+                        # (B*T_pad on the grid, the packed windows on ragged batches) and valid frames as measured
+                        "balance": balance, "phonemes_per_rank": shard_phonemes,
+                        "rows_phase2_max_over_min": round(max(r["rows_phase2"] for r in per_rank) / max(min(r["rows_phase2"] for r in per_rank), 1), 4),
+                        "valid_frames_max_over_min": round(max(r["valid_frames"] for r in per_rank) / max(min(r["valid_frames"] for r in per_rank), 1), 4)},
         "config": {"workload": f"{args.workload}{'_bf16x3' if b3 else ''}{' (ragged lengths)' if args.ragged else ''}{f' (batch overridden: {args.batch})' if args.batch > 0 else ''}: LJSpeech config, batch {B_shard}/GPU x {args.gpus} GPU, phoneme_len {L}, "
                                f"T_pad {T_pad_max}, d_model {cfg['transformer']['decoder_hidden']}, "
                                f"{cfg['transformer']['encoder_layer']}+{cfg['transformer']['decoder_layer']} FFT layers, "
                                f"random-init weights (seed 0, duration bias log({fpp + 1:g}))",
                    "global_batch": B_shard * args.gpus, "valid_frames_per_step": int(frames_total),
-                   "padding": "global-pad" if pad_fn else "per-shard",
+                   "padding": "global-pad" if pad_fn else "per-shard", "shard_balance": balance,
                    "algorithmic_mflop_per_frame": round(flops_frame / 1e6, 2),
                    "end_to_end_tflops": round(flops_frame * value / 1e12, 2)},
         "roofline": {"bound": "mfma", "kernel": "k_conv_gemm (FFN w_1: Conv1d k=9, d->d_inner, bias+ReLU)",
@@ -527,6 +605,9 @@ def main():
                      "frac_rocprof": None if not rocprof_us or not k_launches else round(
                          (k_flops / k_launches) / (rocprof_us * 1e-6) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                      "rocprof_avg_launch_us": rocprof_us,
+                     # where the two figures above that this run did NOT measure come from
+                     "traffic_source": None if traffic is None else "committed profile: profiles/dominant_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/collect_profiles.sh on this launch geometry), replayed, not measured in this run",
+                     "frac_rocprof_source": None if not rocprof_us else "committed profile: the same launches' average in the round's rocprofv3 kernel trace (profiles/dominant_kernel_traffic.json rocprof_timed_avg_us), replayed, not measured in this run",
                      "frac_of_measured_peak": round(achieved_tflops / F32_MFMA_MEASURED_TFLOPS, 4),
                      "launches": int(k_launches), "avg_launch_ms": round(k_ms / max(k_launches, 1), 4),
                      "launches_timed": f"every launch of every {PROF_EVERY}th forward of the timed region (HIP events on the dispatch packets)",
@@ -701,6 +782,31 @@ def main():
         vl["phase1_rows_grid"] = vl["grid"]["phase1_rows"]
         vl["workload"] = f"{args.workload} with ragged lengths (phoneme counts uniform in [L/8, L], B={B_shard})"
         res["variable_length"] = vl
+
+
+    if args.gpus == 1 and not args.no_extras and not b3 and args.workload == "cfg2_b16" and args.batch == 0 and not args.ragged:
+        # The other BASELINE configs on the driver's clock (config 1 = single utterance, 4 = d_model 512 / 6+6 layers / B = 64,
+        # 5 = long-form B = 8 with both length regulators): secondary figures beside the headline workload, each with its own
+        # oracle check on a slice.  A failure of one leg is recorded, never fatal to the line.
+        others = {}
+        check = not args.no_cpu_baseline
+        if check:
+            torch.set_num_threads(min(os.cpu_count() or 1, 64))
+        keep_sd = None
+        for oname in ("cfg1_single", "cfg4_d512", "cfg5_longform", "cfg5_longform_gaussian"):
+            try:
+                if oname == "cfg1_single":     # the headline model's own weights
+                    others[oname], _, _ = run_other_config(oname, dev, model=model, sd=sd, check=check)
+                elif oname == "cfg5_longform_gaussian":  # config 5's weights, the Gaussian regulator wired in
+                    others[oname], _, _ = run_other_config(oname, dev, sd=keep_sd, oracle_slice=2, check=check)
+                else:
+                    others[oname], om, osd = run_other_config(oname, dev, oracle_slice=2 if oname.startswith("cfg5") else 8, check=check)
+                    keep_sd = osd if oname == "cfg5_longform" else None
+                    del om
+            except Exception as e:  # noqa: BLE001
+                others[oname] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
+        res["other_configs"] = others
 
     if args.gpus == 1 and not args.no_cpu_baseline and not args.no_extras:
         # CPU baseline beside it: the oracle (a torch-CPU restatement of the reference forward, "port") on this box's

@@ -79,8 +79,11 @@ constexpr uint32_t ARENA_LAYOUT_VERSION = 5;   // 5: long position table; 4: hea
 constexpr int ARENA_HDR_WORDS = 16;
 static void arena_header(const ns_model* m, uint32_t* w) {
   memset(w, 0, ARENA_HDR_WORDS * sizeof(uint32_t));
-  uint64_t h = 1469598103934665603ull;  // FNV-1a over the config struct
-  const unsigned char* cb = reinterpret_cast<const unsigned char*>(&m->cfg);
+  uint64_t h = 1469598103934665603ull;  // FNV-1a over the config struct — the fields that shape the arena: the run-time switches
+  ns_config lay = m->cfg;               // (how epilogues are launched, when phase 1 packs) are zeroed, ranks may differ in them
+  lay.row_epilogue = 0;
+  lay.phase1_packing = 0;
+  const unsigned char* cb = reinterpret_cast<const unsigned char*>(&lay);
   for (size_t i = 0; i < sizeof(ns_config); ++i) { h ^= cb[i]; h *= 1099511628211ull; }
   w[0] = ARENA_MAGIC; w[1] = ARENA_LAYOUT_VERSION;
   w[2] = (uint32_t)(m->ar.n & 0xffffffffu); w[3] = (uint32_t)((uint64_t)m->ar.n >> 32);
@@ -237,7 +240,14 @@ extern "C" int ns_bind_arena(ns_model* m, void* dev, size_t bytes) {
 extern "C" int ns_adopt_arena(ns_model* m) {
   if (!m || !m->arena) return fail("ns_adopt_arena: no arena bound");
   // the bytes may have arrived on any stream (an RCCL broadcast): wait for the device, then read the header back
+  // (on the device that OWNS the arena, which need not be the caller's current one; the caller's device is restored)
   uint32_t got[ARENA_HDR_WORDS], want[ARENA_HDR_WORDS];
+  int cur_dev = 0;
+  NS_HIP(hipGetDevice(&cur_dev));
+  hipPointerAttribute_t at;
+  NS_HIP(hipPointerGetAttributes(&at, m->arena));
+  struct DevGuard { int d; bool on; ~DevGuard() { if (on) (void)hipSetDevice(d); } } guard{cur_dev, at.device != cur_dev};
+  if (guard.on) NS_HIP(hipSetDevice(at.device));
   NS_HIP(hipDeviceSynchronize());
   NS_HIP(hipMemcpy(got, m->arena + m->hdr, sizeof(got), hipMemcpyDeviceToHost));
   arena_header(m, want);
@@ -603,7 +613,8 @@ static int mha(ns_model* m, const LayerW& L, int d, int H, const float* x, const
     ProfScope ps(m, 1, 4.0 * (double)M * (double)S * (double)d);
     NS_TRY(ps.begin());
     NS_HIP(launch_attention(sc.qkv, lens, B, S, H, d / H, sc.att, sc.att_part, sc.att_part_floats,
-                            (sc.att_part && !sc.pk) ? sc.take_tickets(attention_ticket_ints(B, S, H)) : nullptr, st, cur_rm(sc), ps.timing()));
+                            (sc.att_part && !sc.pk && attention_uses_tickets(B, S, H)) ? sc.take_tickets(attention_ticket_ints(B, S, H)) : nullptr, st, cur_rm(sc),
+                            ps.timing()));
     ps.end();
   }
   return gemm_ln(sc.att, d, m->P(L.fc_w), m->P(L.fc_b), x, sc.t1, out, M, d, d, 1, S, ACT_NONE, m->P(L.ln1_g), m->P(L.ln1_b),

@@ -665,6 +665,13 @@ int attention_split(int B, int S, int H, int dk) {
   return plan_key_split(blocks, (S + 31) / 32, dk, (size_t)B * S, H * dk);
 }
 
+// true when a dense launch of this shape can take the ticketed strip path (the only attention path that draws tickets): the
+// caller spends attention_ticket_ints(B, S, H) of its phase's ticket block only then — the planner's key split of a LARGE launch
+// (k_attention + k_attention_merge) needs the partials scratch but no tickets
+bool attention_uses_tickets(int B, int S, int H) {
+  return B > 0 && S > 0 && (long)((S + 127) / 128) * H * B < ATT_SPLIT_MAX_BLOCKS;
+}
+
 // packed rows: the work list of att_wgs (128-query tile, head) workgroups, longest utterance (S frames) first
 int attention_split_packed(int att_wgs, int S, int dk, size_t Mp, int d) {
   if (att_wgs <= 0 || S <= 0) return 1;

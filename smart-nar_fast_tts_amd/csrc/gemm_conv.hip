@@ -32,6 +32,7 @@
 // group g consumes k = 8g + 4h + e, so each lane reads its 4 steps' operands with ONE ds_read_b128.
 #include <hip/hip_ext.h>
 #include <cstdlib>
+#include <type_traits>
 #include "rowln.h"
 
 namespace ns {
@@ -56,20 +57,35 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // (2) the barrier orders every wave's drain before the ticket, (3) the RMW is performed at L2/memory in ticket order.
 // It is exercised under load by tests/test_gpu_stress.py (thousands of ticketed launches on four streams against the
 // two-launch form, bit for bit).  The counters are zeroed by the first kernel of the forward phase.
-template <int BM, int BN, int BK, int KS, int WGM = 2, int WGN = 2, bool ROWEPI = false, int TICKET = 0>  // TICKET: row width / 256, 0 = off
+// MF: edge of the MFMA tile a wave's output is built from.  32 = v_mfma_f32_32x32x2_f32 (every tile of rounds 1-4); 16 =
+// v_mfma_f32_16x16x4_f32, the 16-ROW family (round 5): the same matrix rate (64 flop / clk / SIMD, tools/lab/mfma_16x16.hip),
+// the same LDS traffic per flop (a ds_read_b128 round feeds 16 rows x 16 k instead of 32 rows x 8 k), but block tiles whose
+// height is any multiple of 16 — so a launch can give every CU ceil(rows / 16 / CUs) x 16 rows instead of a multiple of 32 / 64,
+// which is what makes a forward's time follow B*T between the steps of 256 workgroups.  A launch uses ONE
+// MF for all of its rows (the two instructions walk k in different orders: lane group q of step e holds k = 16g + 4q + e
+// against 8g + 4h + e), so the rows of a launch — replicas of an utterance inside a batch — always carry the same bits.
+template <int BM, int BN, int BK, int KS, int WGM = 2, int WGN = 2, bool ROWEPI = false, int TICKET = 0, int MF = 32>  // TICKET: row width / 256, 0 = off
 __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, int ntn) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type does not exist in the host pass; it only needs the stub
   constexpr int NW = WGM * WGN;       // waves per K-split group, arranged WGM x WGN over the block tile
   constexpr int WM = BM / WGM, WN = BN / WGN;
-  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int TM = WM / MF, TN = WN / MF;
+  constexpr int NR = MF == 32 ? 16 : 4;  // accumulator registers of one MFMA tile
+  constexpr int LG = 64 / MF;            // lane groups of a fragment read: each holds 4 consecutive k of its row
+  constexpr int KG = 4 * LG;             // k values one ds_read_b128 round feeds: 8 (MF 32) or 16 (MF 16)
   constexpr int CPR = BK / 4;         // 16-B chunks per tile row
   constexpr int RPI = 64 / CPR;       // tile rows one wave-wide DMA instruction fills
-  static_assert(TM >= 1 && TN >= 1 && BM % RPI == 0 && BN % RPI == 0, "tile / wave-grid geometry");
+  static_assert(MF == 32 || MF == 16, "MFMA tile edge");
+  static_assert(TM >= 1 && TN >= 1 && WM % MF == 0 && WN % MF == 0 && BM % RPI == 0 && BN % RPI == 0 && BK % KG == 0, "tile / wave-grid geometry");
   constexpr int FSH = (BK == 64) ? 0 : (BK == 32) ? 1 : 2;
   constexpr int FMSK = CPR - 1;
   static_assert(BK == 64 || BK == 32 || BK == 16, "BK");
-  static_assert(!ROWEPI || (KS == 1 && BM <= 2 * BK && BN % 256 == 0 && BM % (WGM * WGN) == 0), "row epilogue: the BM x BN tile is parked in the two B staging buffers");
+  // row epilogue: the tile is parked 2 * BK rows at a time in the two B staging buffers (one pass up to 64 rows at BK = 32)
+  constexpr int EPR = 2 * BK;                      // rows per parking pass
+  constexpr int NPASS = (BM + EPR - 1) / EPR;
+  static_assert(!ROWEPI || (KS == 1 && BN % 256 == 0 && (BM % EPR) % NW == 0 && (BM < EPR || EPR % NW == 0)), "row epilogue: every pass's rows divide over the waves");
   static_assert(!(ROWEPI && TICKET), "a full-row tile needs no ticket");
+  using acc_t = typename std::conditional<MF == 32, f32x16, f32x4>::type;
 
   // Four DISTINCT LDS objects (not [2][...] arrays) and a 2x unrolled K loop with a static buffer index: hipcc tracks
   // in-flight LDS-DMA per LDS object, so a ds_read from As0 does not wait for a DMA that is filling As1.  With one
@@ -175,13 +191,13 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
     }
   };
 
-  f32x16 acc[TM][TN];
+  acc_t acc[TM][TN];
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+      for (int r = 0; r < NR; ++r) acc[mi][ni][r] = 0.f;
 
   // this lane's bias values (KS == 1 epilogues): requested now, consumed after the K loop (in the epilogue the load's
   // latency was fully exposed)
@@ -189,16 +205,17 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
   if constexpr (KS == 1) {
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
-      const int n = n0 + wn0 + ni * 32 + (lane & 31);
+      const int n = n0 + wn0 + ni * MF + (lane & (MF - 1));
       bvp[ni] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
     }
   }
 
-  // fragment read offsets (floats): row (lane&31), slot ((2g + h) ^ f(row)); f is the same for every 32-row tile
-  const int frow = lane & 31, fh = lane >> 5;
-  int foff[BK / 8];
+  // fragment read offsets (floats): row (lane & (MF-1)), slot ((LG g + h) ^ f(row)), h = lane / MF; f is the same for every MFMA tile
+  // of the block tile (MF rows further down the swizzle repeats)
+  const int frow = lane & (MF - 1), fh = lane / MF;
+  int foff[BK / KG];
 #pragma unroll
-  for (int g = 0; g < BK / 8; ++g) foff[g] = frow * BK + (((2 * g + fh) ^ ((frow >> FSH) & FMSK)) * 4);
+  for (int g = 0; g < BK / KG; ++g) foff[g] = frow * BK + (((LG * g + fh) ^ ((frow >> FSH) & FMSK)) * 4);
 
   // this group's slices of the four staging objects
   float* const A0 = As0 + grp * BM * BK;
@@ -219,19 +236,37 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
       const float* as = Ac + wm0 * BK;
       const float* bs = Bc + wn0 * BK;
 #pragma unroll
-      for (int g = 0; g < BK / 8; ++g) {
-        f32x4 a[TM], b[TN];
+      for (int g = 0; g < BK / KG; ++g) {
+        if constexpr (MF == 32) {
+          f32x4 a[TM], b[TN];
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * BK + foff[g]);
+          for (int mi = 0; mi < TM; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * BK + foff[g]);
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * BK + foff[g]);
+          for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * BK + foff[g]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int mi = 0; mi < TM; ++mi)
+            for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], acc[mi][ni], 0, 0, 0);
+              for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], acc[mi][ni], 0, 0, 0);
+        } else {
+          // 16-row family: the B fragments of the wave's columns once, then one A slab at a time (a tall column-split tile has
+          // up to 16 of them: all A fragments live at once would be 64 registers).  Every accumulator still sees its k values
+          // in the order g-major, e-minor whatever the loop nest, so the nest is free to choose.
+          f32x4 b[TN];
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 16 * BK + foff[g]);
+#pragma unroll
+          for (int mi = 0; mi < TM; ++mi) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(as + mi * 16 * BK + foff[g]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[ni][e], acc[mi][ni], 0, 0, 0);
+          }
+        }
       }
     }
     __syncthreads();  // drains this step's DMA (vmcnt) and fences the buffer swap
@@ -241,7 +276,9 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
     if (st + 1 < nsteps) step(st + 1, A1, B1, A0, B0);
   }
 
-  const int ecol = lane & 31, erow = (lane >> 5) * 4;  // C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // C/D layout: 32x32 tile — col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), r < 16; 16x16 tile — col = lane & 15, row = r + 4 (lane >> 4), r < 4
+  const int ecol = lane & (MF - 1);
+  auto crow = [&](int r) { return MF == 32 ? (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) : r + 4 * (lane >> 4); };
   if constexpr (KS > 1) {
     // K-split epilogue, ALL waves of the workgroup: every group parks its partial tile ROW-MAJOR in the (now idle) staging
     // LDS — row stride BN + 8 floats, so the two lane halves of a store (rows 4 apart) land 32 banks apart — and after one
@@ -275,8 +312,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            mine[(wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + erow) * RS + wn0 + ni * 32 + ecol] = acc[mi][ni][r];
+          for (int r = 0; r < NR; ++r)
+            mine[(wm0 + mi * MF + crow(r)) * RS + wn0 + ni * MF + ecol] = acc[mi][ni][r];
     }
     __syncthreads();
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsYs = __builtin_amdgcn_make_buffer_rsrc((void*)p.Y, (short)0, 0x7FFFFFFF, 0x00020000);
@@ -302,82 +339,96 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
   }
 
   if constexpr (ROWEPI) {
-    // Full-row tile (BN == N): park act(acc + bias) as a row-major [BM][BN] tile in the (idle) first B staging buffer,
-    // then every wave takes BM / waves whole rows — one row per wave64, float4 lanes — and runs the row kernel's own
-    // code on them (rowln.h): residual add, LayerNorm, mask / predictor tail, coalesced 1-KB row stores.
-    auto trow = [&](int ml) -> float* { return (ml < BK ? Bs0 : Bs1) + (ml % BK) * BN; };  // rows [0,BK) in Bs0, [BK,2BK) in Bs1
-    // the residual rows this wave will need: all loads issued now, so that their latency runs under the parking stores
-    // and the barrier instead of once per row inside the row loop
-    constexpr int NV = BN / 256, RPW = BM / NW;
-    f32x4 rv[RPW][NV];
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int m = m0 + wid * RPW + rr;
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        rv[rr][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.resid && m < p.M) rv[rr][i] = *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + lane * 4 + i * 256);
-      }
-    }
-    // ... and everything else the row phase reads from memory: the LayerNorm affine of this lane's columns and the mask
-    // lengths of this wave's rows (inside the row loop each was a load -> wait per row)
+    // Full-row tile (BN == N): park act(acc + bias) as row-major [rows][BN] in the (idle) B staging buffers — 2 * BK rows per
+    // pass, rows [0, BK) of a pass in Bs0, [BK, 2 BK) in Bs1 — then every wave takes whole rows — one row per wave64, float4
+    // lanes — and runs the row kernel's own code on them (rowln.h): residual add, LayerNorm, mask / predictor tail, coalesced
+    // 1-KB row stores.  Tiles of up to 64 rows are one pass; the taller ones of the 16-row family take ceil(BM / 64).
+    static_assert(WGM == 1, "full-row tiles put their waves side by side");
+    auto trow = [&](int ml) -> float* { return (ml < BK ? Bs0 : Bs1) + (ml % BK) * BN; };
+    constexpr int NV = BN / 256;
+    // what the row phase reads from memory besides the rows: the LayerNorm affine of this lane's columns (inside the row loop it
+    // was a load -> wait per row)
     f32x4 lng[NV], lnb[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       lng[i] = *reinterpret_cast<const f32x4*>(p.e.ln_g + lane * 4 + i * 256);
       lnb[i] = *reinterpret_cast<const f32x4*>(p.e.ln_b + lane * 4 + i * 256);
     }
-    int tt[RPW];
-    bool masked[RPW];
-    row_batch_masks<RPW>(p.e, p.M, p.S, m0 + wid * RPW, 1, tt, masked);
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-      const int nl = wn0 + ni * 32 + ecol;
-      const float bv = bvp[ni];
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ml = wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + erow;
-          float v = acc[mi][ni][r] + bv;
-          if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
-          else if (p.act == ACT_TANH) v = tanhf(v);
-          trow(ml)[nl] = v;
-        }
-      }
-    }
-    __syncthreads();
-    f32x4 v[RPW][NV];
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr)
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        v[rr][i] = *reinterpret_cast<const f32x4*>(trow(wid * RPW + rr) + lane * 4 + i * 256);
-        if (p.resid) v[rr][i] += rv[rr][i];
-      }
     RowEpilogue e2 = p.e;
     e2.y_out = p.Y;  // (ldy == BN: checked by the launcher)
-    row_batch_finish<NV, RPW>(v, tt, masked, lane, p.epi, e2, p.M, m0 + wid * RPW, 1, lng, lnb);
+    auto pass = [&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+      constexpr int P0 = P * EPR, PR = (BM - P0 < EPR ? BM - P0 : EPR), RPW = PR / NW;
+      if constexpr (P > 0) __syncthreads();  // (the previous pass's rows have been read)
+      // the residual rows this wave will need: all loads issued now, so that their latency runs under the parking stores
+      // and the barrier instead of once per row inside the row loop; the mask lengths of this wave's rows alongside
+      const int mw = m0 + P0 + wid * RPW;
+      f32x4 rv[RPW][NV];
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int m = mw + rr;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          rv[rr][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (p.resid && m < p.M) rv[rr][i] = *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.ldr + lane * 4 + i * 256);
+        }
+      }
+      int tt[RPW];
+      bool masked[RPW];
+      row_batch_masks<RPW>(p.e, p.M, p.S, mw, 1, tt, masked);
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int nl = wn0 + ni * MF + ecol;
+        const float bv = bvp[ni];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+          if ((mi * MF) / EPR != P) continue;  // (compile-time per unrolled mi: MF divides EPR, WGM == 1)
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const int ml = mi * MF + crow(r) - P0;
+            float v = acc[mi][ni][r] + bv;
+            if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
+            else if (p.act == ACT_TANH) v = tanhf(v);
+            trow(ml)[nl] = v;
+          }
+        }
+      }
+      __syncthreads();
+      f32x4 v[RPW][NV];
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          v[rr][i] = *reinterpret_cast<const f32x4*>(trow(wid * RPW + rr) + lane * 4 + i * 256);
+          if (p.resid) v[rr][i] += rv[rr][i];
+        }
+      row_batch_finish<NV, RPW>(v, tt, masked, lane, p.epi, e2, p.M, mw, 1, lng, lnb);
+    };
+    pass(std::integral_constant<int, 0>{});
+    if constexpr (NPASS > 1) pass(std::integral_constant<int, 1>{});
+    if constexpr (NPASS > 2) pass(std::integral_constant<int, 2>{});
+    if constexpr (NPASS > 3) pass(std::integral_constant<int, 3>{});
+    static_assert(NPASS <= 4, "row epilogue: at most 4 parking passes (BM <= 8 BK)");
   } else {
     if constexpr (KS == 1) {
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
-      const int n = n0 + wn0 + ni * 32 + ecol;
+      const int n = n0 + wn0 + ni * MF + ecol;
       if (n >= p.N) continue;
       const float bv = bvp[ni];
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
-        // the tile's 16 residual values first, all loads in flight together: interleaved with the stores (Y may alias
+        // the tile's residual values first, all loads in flight together: interleaved with the stores (Y may alias
         // resid for all the compiler knows) every element paid a full load + store round trip, 16 in a row
-        float rs[16];
+        float rs[NR];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + erow;
+        for (int r = 0; r < NR; ++r) {
+          const int m = m0 + wm0 + mi * MF + crow(r);
           rs[r] = (p.resid && m < p.M) ? p.resid[(size_t)m * p.ldr + n] : 0.f;
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + erow;
+        for (int r = 0; r < NR; ++r) {
+          const int m = m0 + wm0 + mi * MF + crow(r);
           if (m >= p.M) continue;
           float v = acc[mi][ni][r] + bv;
           if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
@@ -410,13 +461,13 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
 #endif
 }
 
-template <int BM, int BN, int BK, int KS = 1, int WGM = 2, int WGN = 2, bool ROWEPI = false, int TICKET = 0>
+template <int BM, int BN, int BK, int KS = 1, int WGM = 2, int WGN = 2, bool ROWEPI = false, int TICKET = 0, int MF = 32>
 static hipError_t launch_t(const ConvGemm& p, hipStream_t st, const LaunchTiming* tm = nullptr) {
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   if (tm && (tm->start || tm->stop))  // the events ride on this kernel's own dispatch packet (kernels.h LaunchTiming)
-    hipExtLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN, ROWEPI, TICKET>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, tm->start, tm->stop, 0, p, ntn);
+    hipExtLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN, ROWEPI, TICKET, MF>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, tm->start, tm->stop, 0, p, ntn);
   else
-    hipLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN, ROWEPI, TICKET>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, p, ntn);
+    hipLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN, ROWEPI, TICKET, MF>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, p, ntn);
   return hipGetLastError();
 }
 

@@ -92,6 +92,7 @@ bool conv_gemm_row_epilogue_ok(int M, int N, int Cin);
 constexpr int ATT_SPLIT_MAX = 16, ATT_SPLIT_MAX_BLOCKS = 128;
 // tickets (nullable): attention_ticket_ints(B, S, H) ZEROED ints for the strip kernel's last-arriver merge (small grids)
 inline int attention_ticket_ints(int B, int S, int H) { return B * H * ((S + 31) / 32); }
+bool attention_uses_tickets(int B, int S, int H);  // false: launch_attention(B, S, H, ...) never touches `tickets` (pass nullptr)
 // rm (packed rows): utterance b's rows start at rm->off[b] and number rm->win[b] <= S (S = the longest window); no split-key path
 hipError_t launch_attention(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, float* scratch,
                             size_t scratch_floats, int* tickets, hipStream_t st, const RowMap* rm = nullptr, const LaunchTiming* tm = nullptr);

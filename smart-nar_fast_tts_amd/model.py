@@ -150,6 +150,9 @@ class FastSpeech2Align:
         self._t_hint = {}         # (B, L) -> T of the last synchronous forward of that shape (capacity guess for the next one)
         self._ws_need = {}        # (kind, B, L, T) -> bytes (ns_*_ws_bytes is a pure function of the config and these)
         self._sd = OrderedDict()  # host copy of what load_state_dict received (for state_dict() / .to())
+        self._user_keys = set()   # inference keys a caller's load_state_dict has supplied so far (strict=True reports the rest)
+        self._init_sd = None      # constructor-equivalent random init, drawn ONCE on first need (introspection or first forward);
+                                  # kept apart from _sd: it is not something a checkpoint load may count as "already loaded"
         self._loaded = False      # a full inference state dict was accepted (load_state_dict) ...
         self._adopted = False     # ... or the packed arena arrived as bytes (adopt_arena)
         self.training = False
@@ -221,8 +224,7 @@ class FastSpeech2Align:
         return key.endswith((".running_mean", ".running_var", ".num_batches_tracked"))
 
     def named_parameters(self, prefix: str = "", recurse: bool = True):
-        self._ensure_host_copy()
-        for k, v in self._sd.items():
+        for k, v in self._ensure_host_copy().items():
             if not self._is_buffer(k):
                 yield (prefix + ("." if prefix else "") + k, torch.from_numpy(np.array(v)).requires_grad_(False))
 
@@ -231,8 +233,7 @@ class FastSpeech2Align:
             yield p
 
     def named_buffers(self, prefix: str = "", recurse: bool = True):
-        self._ensure_host_copy()
-        for k, v in self._sd.items():
+        for k, v in self._ensure_host_copy().items():
             if self._is_buffer(k):
                 yield (prefix + ("." if prefix else "") + k, torch.from_numpy(np.array(v)))
 
@@ -240,12 +241,22 @@ class FastSpeech2Align:
         for _, b in self.named_buffers():
             yield b
 
+    def _default_init(self):
+        """The constructor-equivalent initialisation (model/fastspeech2_align.py:16-28), drawn once: what parameters() reports
+        before anything is loaded IS what the first forward uploads (_ensure_weights), and load_state_dict(strict=False) fills
+        absent keys from the same draw."""
+        if self._init_sd is None:
+            self._init_sd = OrderedDict(wl.default_init_state_dict(self.model_config, self._stats))
+        return self._init_sd
+
     def _ensure_host_copy(self):
-        if not self._sd and self._adopted:
+        """The per-parameter host view for introspection; never touches _sd (what load_state_dict really received)."""
+        if self._sd:
+            return self._sd
+        if self._adopted:
             raise RuntimeError("this model's weights arrived as packed arena bytes (adopt_arena): there is no per-parameter host copy; "
                                "introspect the rank that called load_state_dict()")
-        if not self._sd and self._stats is not None:
-            self._sd = OrderedDict(wl.default_init_state_dict(self.model_config, self._stats))  # what the reference constructor holds
+        return self._default_init() if self._stats is not None else OrderedDict()
 
     def modules(self):
         """The native forward is one object: there are no sub-modules to walk (hooks on sub-modules have nothing to attach to)."""
@@ -294,14 +305,15 @@ class FastSpeech2Align:
             return ""
         return self._lib.ns_last_error().decode()
 
-    def load_state_dict(self, state_dict, strict: bool = True):
+    def load_state_dict(self, state_dict, strict: bool = True, *, _internal: bool = False):
         """Accepts the reference's checkpoint["model"] (utils/model.py:21-22).  ``mel_encoder.*`` (training-only
         aligner) and ``num_batches_tracked`` entries are accepted and ignored.  Like ``nn.Module.load_state_dict``:
         a shape mismatch always raises; an unexpected key raises when ``strict`` and is skipped (and returned)
-        otherwise; missing keys are only possible on the first load and raise when ``strict``.  Every entry is validated
+        otherwise; keys no load has supplied so far raise when ``strict`` and keep their current (constructor-equivalent) values
+        otherwise — a model that already holds a full caller-supplied state dict accepts partial updates.  Every entry is validated
         BEFORE anything is handed to the native side, so a rejected state dict leaves the loaded weights in use."""
         new = OrderedDict()
-        if self._stats is not None and not self._loaded:
+        if self._stats is not None and "variance_adaptor.pitch_bins" not in self._user_keys:  # stats.json defaults, until a load supplied bins
             pb, eb = wl.variance_bins(self.model_config, self._stats)
             new["variance_adaptor.pitch_bins"] = pb
             new["variance_adaptor.energy_bins"] = eb
@@ -325,18 +337,23 @@ class FastSpeech2Align:
             raise RuntimeError("load_state_dict: " + "; ".join(errors))
         merged = OrderedDict(self._sd)
         merged.update(new)
-        missing = []
-        if not self._loaded:  # a partial FIRST load: say which keys are absent before touching native state
-            missing = [k for k in wl.inference_keys(self.model_config) if k not in merged]
-            if missing and strict:
-                raise RuntimeError("load_state_dict: missing key(s): " + ", ".join(missing))
-            if missing:  # strict=False: an nn.Module keeps its constructor's initialisation for keys that did not arrive
-                if self._stats is None:
-                    raise RuntimeError("load_state_dict(strict=False) with missing keys needs <preprocessed_path>/stats.json "
-                                       "for the constructor-equivalent initialisation of the rest: " + ", ".join(missing))
-                init = wl.default_init_state_dict(self.model_config, self._stats)
-                for k in missing:
-                    merged[k] = init[k]
+        # missing = inference keys no CALLER has ever supplied (this load or an earlier one): the constructor-equivalent draw that
+        # _ensure_weights() uploads for a model used before any load, or that parameters() shows, does not count as "loaded" —
+        # a truncated checkpoint must say so under strict=True whatever happened to the model before (nn.Module semantics)
+        provided = self._user_keys | set(new)
+        missing = [k for k in wl.inference_keys(self.model_config) if k not in provided]
+        if missing and strict and not _internal:
+            raise RuntimeError("load_state_dict: missing key(s): " + ", ".join(missing))
+        fill = [k for k in missing if k not in merged]
+        if fill:  # strict=False: an nn.Module keeps its constructor's initialisation for keys that did not arrive
+            if self._stats is None:
+                raise RuntimeError("load_state_dict(strict=False) with missing keys needs <preprocessed_path>/stats.json "
+                                   "for the constructor-equivalent initialisation of the rest: " + ", ".join(fill))
+            init = self._default_init()
+            for k in fill:
+                merged[k] = init[k]
+        if not _internal:
+            self._user_keys = provided
         for k, a in merged.items():
             self._stage(k, a)
         self._sd = merged
@@ -372,7 +389,7 @@ class FastSpeech2Align:
             raise RuntimeError(
                 "weights not loaded: call load_state_dict() (or provide <preprocessed_path>/stats.json for a "
                 "random-init model like the reference constructor's, model/modules.py:41-46)")
-        self.load_state_dict(wl.default_init_state_dict(self.model_config, self._stats))
+        self.load_state_dict(self._default_init(), _internal=True)
 
     # ---- multi-GPU weight replication: rank 0 packs, everyone else adopts the bytes ----
     def arena_tensor(self) -> torch.Tensor:
@@ -383,7 +400,12 @@ class FastSpeech2Align:
         return self._arena
 
     def adopt_arena(self):
-        _lib.check(self._lib.ns_adopt_arena(self._h), "ns_adopt_arena")
+        """The arena bytes arrived from elsewhere (an RCCL broadcast, a file): validate the header and mark the model ready.
+        Runs on the model's own device and waits for it first — the bytes may still be in flight on a collective's stream."""
+        with (torch.cuda.device(self._device) if self._device is not None else contextlib.nullcontext()):
+            if self._device is not None:
+                torch.cuda.synchronize(self._device)
+            _lib.check(self._lib.ns_adopt_arena(self._h), "ns_adopt_arena")
         if not self._loaded:
             self._adopted = True
 
@@ -704,5 +726,7 @@ class FastSpeech2Align:
                 items = tuple(t.clone() if (torch.is_tensor(t) and i != 8) else t for i, t in enumerate(items))
                 status = status.clone()
         out = ForwardOutput(items, status=status, n_vocab=self._cfg.n_vocab)
-        self._last_out = out
+        # check_status() without an argument needs the status words only: keep those, not the output blocks (a long-form batch's
+        # mel / PostNet tensors would otherwise stay pinned until the next forward after the caller has dropped them)
+        self._last_out = ForwardOutput((), status=status, n_vocab=self._cfg.n_vocab)
         return out

@@ -227,6 +227,8 @@ def baseline_size_pins():
     for name, (cfgname, B, L, fpp) in wl.WORKLOADS.items():
         if "+" in cfgname:
             continue  # extension workloads (Gaussian regulator wired in): the reference forward has no such switch
+        if not name.startswith("cfg"):
+            continue  # tile-rule A/B sizes (mid_b4, mid_b10): not BASELINE configs, no pin is committed or read for them
         if name == "cfg3_b128_sharded":
             B = 16  # one rank's shard of config 3 == config 2 with another input seed
         if name == "cfg4_d512":

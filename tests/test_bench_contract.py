@@ -84,6 +84,24 @@ def test_bench_json_contract():
     assert 0 <= chk["bucket_flips"] <= chk["bucket_decisions"] // 100
     if chk["bucket_flips"] == 0:
         assert chk["postnet_max_abs_free_running"] < 1e-3 and chk["frames_over_1e-3_free_running"] == 0
+    # the figures this run replays from the committed profile say so on the line
+    assert (ro["traffic_source"] is None) == (ro["traffic"] is None) and (ro["traffic"] is None or "committed profile" in ro["traffic_source"])
+    assert (ro["frac_rocprof_source"] is None) == (ro["frac_rocprof"] is None)
+    # the other BASELINE configs on the same line (configs 1, 4, 5 and config 5 as worded), each timed and checked against the oracle
+    oc = d["other_configs"]
+    assert set(oc) == {"cfg1_single", "cfg4_d512", "cfg5_longform", "cfg5_longform_gaussian"}
+    for name, o in oc.items():
+        assert "error" not in o, (name, o)
+        assert o["steps"] >= 5 and o["ms_per_step"] > 0 and o["value"] > 0 and o["T_pad"] > 0 and o["valid_frames"] > 0, (name, o)
+        assert abs(o["value"] - o["valid_frames"] / (o["ms_per_step"] * 1e-3)) / o["value"] < 1e-3
+        assert 0 < o["end_to_end_frac_mfma_peak"] <= 1.0 and 0 < o["dominant_kernel"]["frac"] <= 1.0 and o["dominant_kernel"]["launches"] > 0
+        c = o["check_vs_oracle"]
+        assert c["durations_equal"] is True and c["frame_counts_equal"] is True and c["frames_over_1e-3_buckets_pinned"] == 0, (name, c)
+        assert c["postnet_max_abs_buckets_pinned"] < 1e-3
+    assert oc["cfg4_d512"]["workload"].startswith("cfg4_d512: batch 64") and "d_model 512" in oc["cfg4_d512"]["workload"]
+    assert oc["cfg5_longform"]["T_pad"] > 3000 and oc["cfg5_longform_gaussian"]["T_pad"] > 3000 and oc["cfg1_single"]["rows_phase2"] < 1100
+    rs_ = d["rank_spread"]
+    assert rs_["balance"] == "count" and rs_["rows_phase2_max_over_min"] == 1.0 and len(rs_["phonemes_per_rank"]) == 1
 
 
 @pytest.mark.gpu

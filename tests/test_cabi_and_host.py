@@ -368,6 +368,44 @@ def test_module_introspection_surface():
     assert (a, b) == (0, 1) and len(rest) == 10
 
 
+def test_introspection_before_a_load_does_not_count_as_loaded(tmp_path, monkeypatch):
+    """parameters() / named_parameters() / buffers() on a model that has loaded nothing show the
+    constructor-equivalent initialisation WITHOUT turning it into "loaded" state: a truncated checkpoint under strict=True still
+    names its missing keys — also after the model ran on that initialisation — and what introspection showed is what the first
+    forward uploads (one draw, not two)."""
+    import torch
+
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    cfg = wl.model_config("tiny")
+    m = FastSpeech2Align(_stats_dir(tmp_path), cfg)
+    monkeypatch.setattr(FastSpeech2Align, "_bind_arena", lambda self: setattr(self, "_arena", object()))
+    monkeypatch.setattr(FastSpeech2Align, "_upload", lambda self, staged=False: None)
+    m._device = torch.device("cuda", 0)
+    shown = dict(m.named_parameters())
+    assert len(shown) > 80 and len(m._sd) == 0 and not m._loaded and m._user_keys == set()
+    good = wl.synth_state_dict(cfg)
+    part = {k: v for k, v in good.items() if not k.startswith("mel_linear.")}
+    with pytest.raises(RuntimeError, match="missing key.*mel_linear.weight"):
+        m.load_state_dict(part)  # the introspection cache must not stand in for the absent keys
+    assert not m._loaded and len(m._sd) == 0
+    m._ensure_weights()  # what the first forward does on a model nobody loaded: uploads the SAME draw parameters() showed
+    assert m._loaded and m._user_keys == set()
+    np.testing.assert_array_equal(m._sd["mel_linear.weight"], shown["mel_linear.weight"].numpy())
+    np.testing.assert_array_equal(dict(m.named_parameters())["mel_linear.weight"].numpy(), shown["mel_linear.weight"].numpy())
+    with pytest.raises(RuntimeError, match="missing key.*mel_linear.weight"):
+        m.load_state_dict(part)  # still the first CALLER-supplied load: random-init leftovers are not "loaded"
+    np.testing.assert_array_equal(m._sd["mel_linear.weight"], shown["mel_linear.weight"].numpy())
+    missing, _ = m.load_state_dict(part, strict=False)  # explicit opt-in: the absent keys keep the constructor's values
+    assert missing == ["mel_linear.weight", "mel_linear.bias"]
+    np.testing.assert_array_equal(m._sd["mel_linear.weight"], shown["mel_linear.weight"].numpy())
+    np.testing.assert_array_equal(m._sd["mel_linear.bias"], shown["mel_linear.bias"].numpy())
+    m.load_state_dict({k: v for k, v in good.items() if k.startswith("mel_linear.")})  # the rest arrives: nothing missing any more
+    assert m._user_keys >= set(wl.inference_keys(cfg))
+    m.load_state_dict({"mel_linear.bias": np.zeros(80, np.float32)})  # partial update of a fully caller-loaded model: fine
+
+
 def test_launch_plan_invariants_and_settled_choices(lib):
     """The step-aware launch plan (include/nar_fs2.h ns_plan_gemm / ns_plan_attention_split) is host logic: checked here without a
     GPU.  Invariants for every row count: the launches cover exactly M rows, a cut falls on a whole number of the main tile's rows and

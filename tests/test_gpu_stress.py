@@ -106,9 +106,9 @@ def test_fuzz_slice_vs_oracle():
     from tests import fuzz_gpu
 
     small = fuzz_gpu.run(types.SimpleNamespace(iters=44, seed=4, matmul="fp32", big=False), max_seconds=55)
-    big = fuzz_gpu.run(types.SimpleNamespace(iters=5, seed=5, matmul="fp32", big=True), max_seconds=25)
+    big = fuzz_gpu.run(types.SimpleNamespace(iters=8, seed=5, matmul="fp32", big=True), max_seconds=45)
     assert small["checked"] >= 25 and small["packed"] >= 8, small
-    assert big["checked"] >= 2, big
+    assert big["checked"] >= 4, big
     for r in (small, big):
         assert r["worst"]["mel"] < 1e-3 and r["worst"]["postnet"] < 1e-3, r
 

@@ -35,7 +35,17 @@ def _worker(rank, world, port, q):
         lo, hi = sharding.shard_bounds(7, world, rank)
         # global-pad: MAX over ranks of the local longest mel
         gmax = sharding.global_max(torch.tensor(100 + 10 * rank))
-        q.put((rank, ok_bcast, (lo, hi), s_tx.tolist() == tx[lo:hi].tolist(), s_L == L, gmax))
+        # balanced split (LPT on the phoneme counts): every rank computes the same partition from the same host lengths; the
+        # gathered per-rank rows go back into the batch's order through gather_order
+        b_sp, b_tx, b_ln, b_L, b_idx = sharding.shard_batch(sp, tx, ln, world, rank, balance="phonemes", return_index=True)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (b_idx.tolist(), b_tx.tolist(), int(b_ln.sum())))
+        parts = [g[0] for g in gathered]
+        inv = sharding.gather_order(parts)
+        rows = [row for g in gathered for row in g[1]]
+        restored = [rows[int(j)] for j in inv]
+        q.put((rank, ok_bcast, (lo, hi), s_tx.tolist() == tx[lo:hi].tolist(), s_L == L, gmax,
+               (parts, restored == tx.tolist(), [g[2] for g in gathered], b_L == L, b_tx.tolist() == tx[b_idx].tolist())))
     finally:
         dist.destroy_process_group()
 
@@ -64,9 +74,41 @@ def test_two_rank_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert [r[2] for r in res] == [(0, 4), (4, 7)]
-    for rank, ok_bcast, span, same_rows, same_L, gmax in res:
+    for rank, ok_bcast, span, same_rows, same_L, gmax, bal in res:
         assert ok_bcast and same_rows and same_L
         assert gmax == 110  # max(100, 110)
+        parts, restored, loads, same_L2, own_rows = bal
+        assert restored and same_L2 and own_rows
+        assert sorted(i for p in parts for i in p) == list(range(7)) and [len(p) for p in parts] == [4, 3]  # a partition, counts kept
+        # src_lens [12, 5, 9, 1, 12, 3, 8] = 50 phonemes: contiguous gives 27 / 23, LPT 25 / 25
+        assert loads == [25, 25], loads
+
+
+def test_balanced_split_properties():
+    """sharding.shard_indices(balance="phonemes"): a partition with the contiguous split's counts, never worse than it in the
+    heaviest shard's phoneme load, deterministic, and the identity for one rank; gather_order inverts it."""
+    import numpy as np
+
+    from smart_nar_fast_tts_amd.sharding import gather_order, shard_bounds, shard_indices
+
+    rs = np.random.RandomState(3)
+    for n, w in ((0, 2), (1, 2), (7, 2), (16, 8), (128, 8), (129, 8), (50, 3)):
+        lens = rs.randint(1, 129, size=n)
+        cnt = shard_indices(lens, w, "count")
+        bal = shard_indices(lens, w, "phonemes")
+        assert [len(p) for p in bal] == [shard_bounds(n, w, r)[1] - shard_bounds(n, w, r)[0] for r in range(w)]
+        assert sorted(int(i) for p in bal for i in p) == list(range(n))
+        assert all(np.all(np.diff(p) > 0) for p in bal if len(p) > 1)
+        heavy = lambda parts: max([int(lens[p].sum()) for p in parts] + [0])  # noqa: E731
+        assert heavy(bal) <= heavy(cnt)
+        assert all(np.array_equal(a, b) for a, b in zip(bal, shard_indices(lens, w, "phonemes")))
+        inv = gather_order(bal)
+        cat = np.concatenate(bal) if n else np.zeros(0, dtype=np.int64)
+        assert np.array_equal(cat[inv], np.arange(n))
+    assert np.array_equal(shard_indices([5, 9, 2], 1, "phonemes")[0], [0, 1, 2])
+    lens = np.random.RandomState(7).randint(16, 129, size=128)
+    loads = [int(lens[p].sum()) for p in shard_indices(lens, 8, "phonemes")]
+    assert max(loads) - min(loads) <= 8, loads  # (contiguous: a spread of hundreds on the same draw)
 
 
 def _gpu_worker(rank, world, port, q):
