@@ -217,13 +217,18 @@ int ns_op_attention_core(const float* qkv, const int64_t* lens, int B, int S, in
 
 /* Introspection of the step-aware launch plan (csrc/gemm_conv.hip plan_rows, csrc/attention.hip plan_key_split); host-side, no GPU
  * needed.  ns_plan_gemm: how a plain Conv1D-as-GEMM of M rows, N output channels, kernel size KW over Cin input channels
- * (transformer/SubLayers.py:87-95 over an arbitrary B*T) is launched: out = {BM, BN, rows} of the main launch and {BM, BN, rows} of
- * the remainder launch (zeros: a single launch).  Returns 1 when the planner covers the shape, 0 when it is left to the small-grid
- * K-split ladder (few tiles) or the narrow-channel rules (then out is zeroed).  Every planner tile sums a row's contraction in the
- * same order, so the cut never shows in the bits.
+ * (transformer/SubLayers.py:87-95 over an arbitrary B*T) is launched: out = {BM, BN, rows} of the main launch, {BM, BN, rows} of
+ * the remainder launch (zeros: a single launch), the edge of the MFMA tile the launch(es) are built from — 32, or 16 for the 16-row
+ * family whose tile HEIGHT (any multiple of 16) is chosen for the row count — and the cost model's estimate in microseconds.
+ * Returns 1 when the planner covers the shape, 0 when it is left to the small-grid K-split ladder (few tiles) or the
+ * narrow-channel rules (then out is zeroed).  All rows of one GEMM are summed in one order: a cut is only ever made between tiles
+ * of the 32-row family, which share it, so it never shows in the bits.
+ * ns_plan_row_tile: height of the full-row tile (GEMM + LayerNorm / predictor-tail epilogue, N = 256 or 512 = one activation
+ * row) for M rows: 32, or a multiple of 16 up to 128 when that gives the fullest CU fewer rows; 0 for other widths.
  * ns_plan_attention_split: key ranges per 128-query tile of a dense attention launch (1 = none; 16 = the small-grid paths' own
  * sizing, the value the workspace is reserved for). */
-int ns_plan_gemm(int M, int N, int Cin, int KW, int32_t out[6]);
+int ns_plan_gemm(int M, int N, int Cin, int KW, int32_t out[8]);
+int ns_plan_row_tile(int M, int N);
 int ns_plan_attention_split(int B, int S, int H, int dk);
 
 /* Measurement hook for bench.py's roofline legs: while enabled, the launches of the three heaviest kernels inside

@@ -1155,11 +1155,15 @@ extern "C" int ns_op_variance_embedding(ns_model* m, int which, const float* x, 
   return predictor(m, m->pred[1 + which], x, (const long long*)lens, B, S, control, target, pred, m->P(bins), m->P(emb), nullptr, x_out,
                    sc, st);
 }
-extern "C" int ns_plan_gemm(int M, int N, int Cin, int KW, int32_t out[6]) {
-  int o[6] = {0, 0, 0, 0, 0, 0};
+extern "C" int ns_plan_gemm(int M, int N, int Cin, int KW, int32_t out[8]) {
+  int o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool planned = conv_gemm_plan(M, N, Cin, KW, o);
-  if (out) for (int i = 0; i < 6; ++i) out[i] = planned ? o[i] : 0;
+  if (out) for (int i = 0; i < 8; ++i) out[i] = planned ? o[i] : 0;
   return planned ? 1 : 0;
+}
+extern "C" int ns_plan_row_tile(int M, int N) {
+  if (M <= 0 || (N != 256 && N != 512)) return 0;
+  return conv_gemm_row_tile(M, N);
 }
 extern "C" int ns_plan_attention_split(int B, int S, int H, int dk) { return attention_split(B, S, H, dk); }
 

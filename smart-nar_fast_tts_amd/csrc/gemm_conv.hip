@@ -529,8 +529,62 @@ static float tile_time(int t, long M, int N, int chunks) {
   // between near-ties the taller tile (fewer passes over the weights, settled by forward A/B runs in round 3) keeps the launch
   return (a + b + b * more * (float)(steps - 1)) * (1.0f + 0.01f * (float)t);
 }
-static hipError_t launch_tile(int t, const ConvGemm& p, hipStream_t st, const LaunchTiming* tm) {
-  switch (t) {
+// ---- the 16-row family (MF = 16, round 5) ------------------------------------------------------------------------------------------
+// A launch whose time is a staircase in units of 256 workgroups gives every CU ceil(row tiles / 256) x BM rows: with 32 / 64 / 128 /
+// 256-row tiles a batch between two steps pays for rows it does not have (B = 9 x 1010 rows: 35.5 rows per CU and column tile,
+// 64 taken).  The 16-row family picks the tile HEIGHT for the launch — BM = 16 s, s = ceil(rows / 16 / row tiles per step) — so the
+// launch is one (or k) full step(s) of tiles that are only as tall as the rows ask for, and it is ONE launch: no remainder, no cut.
+//   F16W: 16 s x 256, 16 waves side by side (16 columns each, s slabs of 16 rows per wave), s = 3 ... 16; two workgroups per CU up to s = 4
+//   F16N: 16 s x 128, 8 waves side by side, s = 3 ... 10; two or three workgroups per CU
+// Lab (tools/lab/gemm_lab_mf16.hip, same-run, us): k=9 256->1024 M = 9090 378 (128x256 on 8192 rows + 64x64 on 898) -> 354-357 (144x256),
+// M = 11 110 474 -> 432 (176x256), M = 10 490 471 -> 422-427; k=5 512->512 M = 9090 251 -> 211-216 (48x128 / 144x128), M = 17 170 414 -> 388
+// (144x256); QKV M = 9090 46.2 -> 41.2 (112x256); at full steps of the tall 32-row tiles (M = 16 160) nothing changes.  Same tile height:
+// 128x256 317 (MF 16) vs 324 (MF 32, 4x4 waves), 256x256 615 vs 597 (8x2 waves): the matrix rate and the LDS traffic per flop are the same.
+enum TileFam { F32 = 0, F16W = 1, F16N = 2 };
+struct TileSel { int fam, id; };  // F32: id = TileId; F16W / F16N: id = slabs (BM = 16 id)
+static int sel_bm(TileSel t) { return t.fam == F32 ? kTile[t.id].bm : 16 * t.id; }
+static int sel_bn(TileSel t) { return t.fam == F32 ? kTile[t.id].bn : t.fam == F16W ? 256 : 128; }
+constexpr int F16W_MIN = 3, F16W_MAX = 16, F16N_MIN = 3, F16N_MAX = 10;
+static bool tile16_enabled() {  // NS_TILE16=0: the planner without the 16-row family (A/B runs; read once)
+  static const bool on = [] { const char* e = getenv("NS_TILE16"); return !(e && e[0] == '0'); }();
+  return on;
+}
+// per-CU rows of a launch of `wgs` equal workgroups (the dispatcher hands a CU its next workgroup when a slot frees; co-resident
+// workgroups share the CU's matrix pipe, so what counts is how many land on the fullest CU) times the per-row, per-chunk rate
+static float tile16_time(int fam, int slabs, long M, int N, int chunks) {
+  const int bm = 16 * slabs, bn = fam == F16W ? 256 : 128;
+  const long wgs = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  const float steps = (float)((wgs + 255) / 256);
+  const float rows = (float)bm * (fam == F16W ? 1.0f : 0.5f);  // in rows of a 256-column tile
+  // 0.0281 us per row and K chunk = the 128x256 tile's 3.6 us per chunk (forward traces); the 128-column form re-reads the activation
+  // panel twice as often (+2 %); a step's ramp and drain, the launch itself
+  const float b1 = 0.0281f * rows * (fam == F16N ? 1.02f : 1.0f);
+  return 5.0f + 0.0016f * rows * (float)chunks + steps * (8.0f + b1 * (float)chunks);
+}
+template <int S>
+static hipError_t launch_f16w(const ConvGemm& p, hipStream_t st, const LaunchTiming* tm) { return launch_t<16 * S, 256, 32, 1, 1, 16, false, 0, 16>(p, st, tm); }
+template <int S>
+static hipError_t launch_f16n(const ConvGemm& p, hipStream_t st, const LaunchTiming* tm) { return launch_t<16 * S, 128, 32, 1, 1, 8, false, 0, 16>(p, st, tm); }
+static hipError_t launch_tile(TileSel t, const ConvGemm& p, hipStream_t st, const LaunchTiming* tm) {
+  if (t.fam == F16W) {
+    switch (t.id) {
+      case 3: return launch_f16w<3>(p, st, tm); case 4: return launch_f16w<4>(p, st, tm); case 5: return launch_f16w<5>(p, st, tm);
+      case 6: return launch_f16w<6>(p, st, tm); case 7: return launch_f16w<7>(p, st, tm); case 8: return launch_f16w<8>(p, st, tm);
+      case 9: return launch_f16w<9>(p, st, tm); case 10: return launch_f16w<10>(p, st, tm); case 11: return launch_f16w<11>(p, st, tm);
+      case 12: return launch_f16w<12>(p, st, tm); case 13: return launch_f16w<13>(p, st, tm); case 14: return launch_f16w<14>(p, st, tm);
+      case 15: return launch_f16w<15>(p, st, tm); case 16: return launch_f16w<16>(p, st, tm);
+      default: return hipErrorInvalidValue;
+    }
+  }
+  if (t.fam == F16N) {
+    switch (t.id) {
+      case 3: return launch_f16n<3>(p, st, tm); case 4: return launch_f16n<4>(p, st, tm); case 5: return launch_f16n<5>(p, st, tm);
+      case 6: return launch_f16n<6>(p, st, tm); case 7: return launch_f16n<7>(p, st, tm); case 8: return launch_f16n<8>(p, st, tm);
+      case 9: return launch_f16n<9>(p, st, tm); case 10: return launch_f16n<10>(p, st, tm);
+      default: return hipErrorInvalidValue;
+    }
+  }
+  switch (t.id) {
     case T256: return launch_t<256, 256, 32, 1, 8, 2>(p, st, tm);
     case T128: return launch_t<128, 256, 32, 1, 4, 4>(p, st, tm);
     case T64W: return launch_t<64, 256, 32, 1, 2, 4>(p, st, tm);
@@ -539,10 +593,10 @@ static hipError_t launch_tile(int t, const ConvGemm& p, hipStream_t st, const La
     default: return launch_t<32, 128, 32, 1, 1, 4>(p, st, tm);
   }
 }
-struct RowPlan { int main_tile, main_rows, rem_tile; float us; };  // main_rows == 0: one launch of rem_tile
+struct RowPlan { TileSel main; int main_rows; TileSel rem; float us; };  // main_rows == 0: one launch of rem
 static RowPlan plan_rows(long M, int N, int chunks) {
   constexpr float CUT_US = 3.0f;  // a second launch: its ramp is in a(tile), this is the boundary itself
-  RowPlan best{-1, 0, T64, 1e30f};
+  RowPlan best{{F32, -1}, 0, {F32, T64}, 1e30f};
   // short contractions (QKV, fc: K = d, 8-16 chunks): prologue and epilogue weigh as much as the K loop, and three 64x128 workgroups
   // per CU interleave them better than one tall 16-wave tile — settled by forward A/B in round 3 (config 2 5.476 -> 5.456 ms) and
   // again by the model's own margin in round 4 (B = 20 QKV: 256x256 one step 83 us in the lab against 77 us on 64x128)
@@ -550,7 +604,7 @@ static RowPlan plan_rows(long M, int N, int chunks) {
   for (int t = first; t < N_TILES; ++t) {
     if (kTile[t].bn > N && t != T32 && t != T64N && t != T64) continue;  // (a 256-wide tile on a narrower output: never)
     const float c = tile_time(t, M, N, chunks);
-    if (c < best.us) best = RowPlan{-1, 0, t, c};
+    if (c < best.us) best = RowPlan{{F32, -1}, 0, {F32, t}, c};
   }
   for (int t = first; t <= T64; ++t) {
     if (kTile[t].bn > N) continue;
@@ -564,24 +618,57 @@ static RowPlan plan_rows(long M, int N, int chunks) {
       for (int r = t + 1; r < N_TILES; ++r) {
         if (kTile[r].bn > N && r < T64) continue;
         const float c = cm + CUT_US + tile_time(r, rest, N, chunks);
-        if (c < best.us) best = RowPlan{t, (int)rows, r, c};
+        if (c < best.us) best = RowPlan{{F32, t}, (int)rows, {F32, r}, c};
       }
     }
+  }
+  // the 16-row family: one launch, the tile height chosen for the row count.  It has to beat the 32-row plans by 1 % (between
+  // near-ties the plans that forward A/B runs settled at the BASELINE configurations stay)
+  if (tile16_enabled()) {
+    if (N % 256 == 0)
+      for (int sl = F16W_MIN; sl <= F16W_MAX; ++sl) {
+        const float c = tile16_time(F16W, sl, M, N, chunks) * 1.01f;
+        if (c < best.us) best = RowPlan{{F32, -1}, 0, {F16W, sl}, c};
+      }
+    if (N % 128 == 0)
+      for (int sl = F16N_MIN; sl <= F16N_MAX; ++sl) {
+        const float c = tile16_time(F16N, sl, M, N, chunks) * 1.01f;
+        if (c < best.us) best = RowPlan{{F32, -1}, 0, {F16N, sl}, c};
+      }
   }
   return best;
 }
 
 // the plan of a plain (no row epilogue) GEMM of this shape, for introspection (nar_fs2.h ns_plan_gemm): false = the shape is below
 // the planner's range (small-grid K-split ladder) or outside it (Cin % 32 != 0, N < 128), nothing is written
-bool conv_gemm_plan(int M, int N, int Cin, int KW, int out[6]) {
+bool conv_gemm_plan(int M, int N, int Cin, int KW, int out[8]) {
   if (!launch_planner_enabled() || M <= 0 || N < 128 || Cin % 32 != 0) return false;
   const long rows64 = ((long)M + 63) / 64;
   if (rows64 * ((N + 127) / 128) <= 256) return false;
   const RowPlan pl = plan_rows(M, N, KW * (Cin / 32));
-  const int mt = pl.main_rows ? pl.main_tile : pl.rem_tile;
-  out[0] = kTile[mt].bm; out[1] = kTile[mt].bn; out[2] = pl.main_rows ? pl.main_rows : M;
-  out[3] = pl.main_rows ? kTile[pl.rem_tile].bm : 0; out[4] = pl.main_rows ? kTile[pl.rem_tile].bn : 0; out[5] = pl.main_rows ? M - pl.main_rows : 0;
+  const TileSel mt = pl.main_rows ? pl.main : pl.rem;
+  out[0] = sel_bm(mt); out[1] = sel_bn(mt); out[2] = pl.main_rows ? pl.main_rows : M;
+  out[3] = pl.main_rows ? sel_bm(pl.rem) : 0; out[4] = pl.main_rows ? sel_bn(pl.rem) : 0; out[5] = pl.main_rows ? M - pl.main_rows : 0;
+  out[6] = mt.fam == F32 ? 32 : 16;
+  out[7] = (int)(pl.us + 0.5f);
   return true;
+}
+
+// Height of the FULL-ROW tile (LayerNorm / predictor-tail epilogue; N = 256 or 512 columns = one activation row) for M rows.  The
+// 32-row tile's launches are a staircase too — 285 tiles (B = 9) put two on 29 CUs and everyone waits for those: 64 rows per CU
+// for 35.5 — so the height is the multiple of 16 that gives the fullest CU the fewest rows, BM x ceil(row tiles / 256); ties keep
+// the 32-row tile (MF 32) the BASELINE configurations were settled on.  Lab (us): w_2 + LN M = 9090 75 -> 60 (48 rows), M = 17 170
+// 117 -> 98 (80 rows); fc + LN 26.8 -> 22.4, 40.3 -> 35.1; predictor conv + LN 59 -> 47.5, 92 -> 76.5; M = 16 160 unchanged (64 = 2 x 32).
+int conv_gemm_row_tile(int M, int N) {
+  if (!launch_planner_enabled() || !tile16_enabled()) return 32;
+  const int max_bm = N == 256 ? 128 : 112;  // (512 columns: the two B staging buffers alone are 128 KB of the CU's 160)
+  long best = 32 * ((((long)M + 31) / 32 + 255) / 256);
+  int bm = 32;
+  for (int c = 48; c <= max_bm; c += 16) {
+    const long rows = (long)c * ((((long)M + c - 1) / c + 255) / 256);
+    if (rows < best) { best = rows; bm = c; }
+  }
+  return bm;
 }
 
 static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bool allow_split, const LaunchTiming* tm);
@@ -615,8 +702,27 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
   if (p.epi != EPI_NONE) {
     // full-row tile: 32 rows x N columns, N / 32 waves side by side with one 32x32 MFMA tile each
     if (!conv_gemm_row_epilogue_ok(p.M, p.N, p.Cin) || (p.epi == EPI_LN && p.ldy != p.N) || (p.resid && (p.ldr & 3))) return hipErrorInvalidValue;
-    if (p.N == 256) return launch_t<32, 256, 32, 1, 1, 8, true>(p, st, tm);
-    return launch_t<32, 512, 32, 1, 1, 16, true>(p, st, tm);
+    // (the height follows the row count: conv_gemm_row_tile above; 16 waves side by side in the 16-row family)
+    const int bm = conv_gemm_row_tile(p.M, p.N);
+    if (p.N == 256) {
+      switch (bm) {
+        case 48: return launch_t<48, 256, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
+        case 64: return launch_t<64, 256, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
+        case 80: return launch_t<80, 256, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
+        case 96: return launch_t<96, 256, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
+        case 112: return launch_t<112, 256, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
+        case 128: return launch_t<128, 256, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
+        default: return launch_t<32, 256, 32, 1, 1, 8, true>(p, st, tm);
+      }
+    }
+    switch (bm) {
+      case 48: return launch_t<48, 512, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
+      case 64: return launch_t<64, 512, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
+      case 80: return launch_t<80, 512, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
+      case 96: return launch_t<96, 512, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
+      case 112: return launch_t<112, 512, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
+      default: return launch_t<32, 512, 32, 1, 1, 16, true>(p, st, tm);
+    }
   }
   const bool bk32 = (p.Cin % 32) == 0;
   // Tile / wave-grid choice (tools/lab sweeps on the path's shapes, MI355X, same-run comparisons).  What wins is
@@ -643,11 +749,11 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
   // partial step whatever the tile, and the small-grid ladder at the end of this function (in-workgroup K split) is faster.
   if (launch_planner_enabled() && allow_split && bk32 && p.N >= 128 && wgs(rows64, 128) > 256) {
     const RowPlan pl = plan_rows(p.M, p.N, p.KW * (p.Cin / 32));
-    if (pl.main_rows == 0) return launch_tile(pl.rem_tile, p, st, tm);
+    if (pl.main_rows == 0) return launch_tile(pl.rem, p, st, tm);
     const LaunchTiming t0{tm ? tm->start : nullptr, nullptr}, t1{nullptr, tm ? tm->stop : nullptr};
-    const hipError_t e = launch_tile(pl.main_tile, row_range(p, 0, pl.main_rows), st, &t0);
+    const hipError_t e = launch_tile(pl.main, row_range(p, 0, pl.main_rows), st, &t0);
     if (e != hipSuccess) return e;
-    return launch_tile(pl.rem_tile, row_range(p, pl.main_rows, p.M - pl.main_rows), st, &t1);
+    return launch_tile(pl.rem, row_range(p, pl.main_rows, p.M - pl.main_rows), st, &t1);
   }
   // Mid-size row counts on the long-K convolutions (FFN k=9, PostNet k=5): a few utterances, or a packed variable-length
   // batch.  Between the small-grid ladder's 512 workgroups and the point where whole rounds of the 64-row tiles average out,
@@ -713,7 +819,13 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
     const int nch = p.KW * (p.Cin / 32);
     if (wgs(rows32, 32) <= 256) return nch >= 16 ? launch_t<32, 32, 32, 8, 1, 1>(p, st, tm) : launch_t<32, 32, 32, 4, 1, 1>(p, st, tm);
     if (wgs(rows32, 64) <= 256) return launch_t<32, 64, 32, 4, 1, 2>(p, st, tm);
-    if (wgs(rows32, 128) <= 512) return launch_t<32, 128, 32, 2, 1, 4>(p, st, tm);
+    if (wgs(rows32, 128) <= 512) {
+      // between one and two rounds of the 32x128 rung (B = 9 ... 12 encoder grids: 288 workgroups took as long as 512): the same
+      // rung 48 rows tall, one round (16-row family; tools/lab/gemm_lab_mf16.hip, k9 256->1024: M = 1152 80.5 -> 63.1 us, 1408 79.6 -> 63.9)
+      if (launch_planner_enabled() && tile16_enabled() && wgs(rows32, 128) > 256 && wgs((p.M + 47) / 48, 128) <= 256)
+        return launch_t<48, 128, 32, 2, 1, 4, false, 0, 16>(p, st, tm);
+      return launch_t<32, 128, 32, 2, 1, 4>(p, st, tm);
+    }
     return launch_t<64, 64, 32>(p, st, tm);
   }
   if (wgs(rows32, 32) <= 512) return launch_t<32, 32, 16, 4, 1, 1>(p, st, tm);

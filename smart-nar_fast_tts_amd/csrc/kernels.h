@@ -71,7 +71,10 @@ struct ConvGemm {
 // A plan of several launches gets `start` on its first and `stop` on its last kernel.  nullptr / {nullptr, nullptr} = untimed.
 struct LaunchTiming { hipEvent_t start, stop; };
 hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st, const LaunchTiming* tm = nullptr);
-bool conv_gemm_plan(int M, int N, int Cin, int KW, int out[6]);  // {bm, bn, rows} of the main launch, {bm, bn, rows} of the remainder (0 = none)
+// {bm, bn, rows} of the main launch, {bm, bn, rows} of the remainder (0 = none), the MFMA tile edge of the launch(es) (32 / 16),
+// the cost model's estimate in us
+bool conv_gemm_plan(int M, int N, int Cin, int KW, int out[8]);
+int conv_gemm_row_tile(int M, int N);  // height of the full-row (LayerNorm epilogue) tile for M rows of N = 256 / 512 columns
 // NS_PLAN=0 in the environment: the round-3 one-tile-per-launch rules (A/B runs of the planner; read once)
 bool launch_planner_enabled();
 // opt-in "bf16x3" precision mode (gemm_bf16x3.hip): same contraction from an exact 3-way bf16 split of both operands

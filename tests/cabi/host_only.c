@@ -19,7 +19,7 @@ int main(int argc, char** argv) {
   void* so;
   ns_config c;
   ns_model* m = 0;
-  int32_t plan[6];
+  int32_t plan[8];
   if (argc < 2) return 2;
   so = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
   if (!so) { printf("dlopen: %s\n", dlerror()); return 3; }
@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
     if (arena(m) < 100u * 1000u * 1000u) return 6;
     c.d_dec = 512; /* encoder_hidden != decoder_hidden: refused with a message */
     { ns_model* bad = 0; if (create(&c, &bad) == 0 || strlen(last_error()) == 0) return 7; }
-    if (plan_gemm(16160, 1024, 256, 9, plan) != 1 || plan[0] != 256 || plan[1] != 256 || plan[2] != 16160 || plan[5] != 0) return 8;
+    if (plan_gemm(16160, 1024, 256, 9, plan) != 1 || plan[0] != 256 || plan[1] != 256 || plan[2] != 16160 || plan[5] != 0 || plan[6] != 32 || plan[7] <= 0) return 8;
     if (att_split(16, 1010, 2, 128) != 1) return 9;
     destroy(m);
   }

@@ -414,30 +414,46 @@ def test_launch_plan_invariants_and_settled_choices(lib):
     _, lib = lib
 
     def plan(M, N, Cin, KW):
-        o = (C.c_int32 * 6)()
+        o = (C.c_int32 * 8)()
         return lib.ns_plan_gemm(M, N, Cin, KW, o), list(o)
 
     shapes = [(1024, 256, 9), (512, 512, 5), (768, 256, 1), (256, 1024, 1)]  # FFN w_1, PostNet 512->512, QKV, FFN w_2 (plain form)
+    fam16 = 0
     for N, Cin, KW in shapes:
         for M in list(range(3000, 36000, 317)) + [8192, 8193, 16384, 16385, 65536 + 1088]:
-            ok, (bm, bn, rows, rbm, rbn, rrows) = plan(M, N, Cin, KW)
+            ok, (bm, bn, rows, rbm, rbn, rrows, mf, us) = plan(M, N, Cin, KW)
             if not ok:
                 assert ((M + 63) // 64) * ((N + 127) // 128) <= 256, (M, N)
                 continue
-            assert rows + rrows == M and bm in (32, 64, 128, 256) and bn in (64, 128, 256), (M, N, bm, bn)
+            assert rows + rrows == M and mf in (16, 32) and us > 0 and bn in (64, 128, 256), (M, N, bm, bn)
+            if mf == 16:  # the 16-row family: ONE launch, any multiple of 16 rows per tile, 128 or 256 columns
+                fam16 += 1
+                assert rrows == 0 and bm % 16 == 0 and 48 <= bm <= 256 and bn in (128, 256) and N % bn == 0, (M, N, bm, bn)
+                continue
+            assert bm in (32, 64, 128, 256), (M, N, bm, bn)
             if rrows:
                 ntn = -(-N // bn)
                 per = (256 // ntn) * bm  # rows of one full step of the main tile
                 assert rows % per == 0 and rows % bm == 0 and rbm <= bm and rbm * rbn <= bm * bn, (M, N, bm, bn, rows, rbm, rbn, rrows)
             if Cin * KW <= 512:
                 assert bm <= 64, ("short contractions stay on the 8-wave tiles", M, N, bm, bn)
-    # BASELINE configurations (B*T_pad rows): config 2, config 5, config 4
-    assert plan(16160, 1024, 256, 9) == (1, [256, 256, 16160, 0, 0, 0])      # FFN w_1: one round of the 256x256 tile
-    assert plan(16160, 512, 512, 5) == (1, [128, 256, 16160, 0, 0, 0])       # PostNet 512->512: one round of 128x256
-    assert plan(16160, 768, 256, 1) == (1, [64, 128, 16160, 0, 0, 0])        # QKV
-    assert plan(31248, 1024, 256, 9) == (1, [256, 256, 31248, 0, 0, 0])      # config 5: two rounds
+    assert fam16 > 50, fam16  # between the steps of the tall tiles the family is what the plan picks
+    # BASELINE configurations (B*T_pad rows): config 2, config 5, config 4 — settled by forward A/B runs, unchanged by the 16-row family
+    assert plan(16160, 1024, 256, 9)[1][:7] == [256, 256, 16160, 0, 0, 0, 32]      # FFN w_1: one round of the 256x256 tile
+    assert plan(16160, 512, 512, 5)[1][:7] == [128, 256, 16160, 0, 0, 0, 32]       # PostNet 512->512: one round of 128x256
+    assert plan(16160, 768, 256, 1)[1][:7] == [64, 128, 16160, 0, 0, 0, 32]        # QKV
+    assert plan(31248, 1024, 256, 9)[1][:7] == [256, 256, 31248, 0, 0, 0, 32]      # config 5: two rounds
     ok, p4 = plan(66624, 1024, 512, 9)                                       # config 4: four full rounds + the remaining 1088 rows
     assert ok and p4[:3] == [256, 256, 65536] and p4[5] == 1088 and p4[3] <= 64
+    # between the steps (B = 9, 11 utterances of 1010 frames; the ragged config-2 batch's packed rows): one launch of a tile as tall as
+    # the rows ask for — 9090 rows x 4 column tiles = 64 row tiles of 144 rows = 256 workgroups
+    assert plan(9090, 1024, 256, 9)[1][:7] == [144, 256, 9090, 0, 0, 0, 16]
+    assert plan(11110, 1024, 256, 9)[1][:7] == [176, 256, 11110, 0, 0, 0, 16]
+    assert plan(10490, 1024, 256, 9)[1][6] == 16 and plan(9090, 512, 512, 5)[1][6] == 16
+    # the full-row (GEMM + LayerNorm epilogue) tile: as tall as the fullest CU needs, 32 on ties
+    rt = {M: lib.ns_plan_row_tile(M, 256) for M in (8080, 9090, 10490, 11110, 12120, 16160, 17170, 20200, 31248)}
+    assert rt == {8080: 32, 9090: 48, 10490: 48, 11110: 48, 12120: 48, 16160: 32, 17170: 80, 20200: 80, 31248: 32}, rt
+    assert lib.ns_plan_row_tile(66624, 512) == 32 and lib.ns_plan_row_tile(9090, 512) == 48 and lib.ns_plan_row_tile(9090, 300) == 0
     # below the planner's range: the small-grid K-split ladder (encoder rows, single utterances)
     assert plan(2048, 1024, 256, 9)[0] == 0 and plan(788, 512, 512, 5)[0] == 0 and plan(16160, 80, 512, 5)[0] == 0
     # attention: one workgroup per CU -> a key split only when the last round of 256 fills badly

@@ -489,10 +489,10 @@ def _plan_of(m, M, N, Cin, KW):
     """include/nar_fs2.h ns_plan_gemm as a dict, or None below the planner's range"""
     import ctypes as C
 
-    o = (C.c_int32 * 6)()
+    o = (C.c_int32 * 8)()
     if not m._lib.ns_plan_gemm(int(M), int(N), int(Cin), int(KW), o):
         return None
-    return {"main": (o[0], o[1], o[2]), "rem": (o[3], o[4], o[5])}
+    return {"main": (o[0], o[1], o[2]), "rem": (o[3], o[4], o[5]), "mfma_edge": o[6], "model_us": o[7]}
 
 
 @pytest.mark.parametrize("B", [9, 11, 17, 20])
@@ -515,8 +515,11 @@ def test_planner_shapes_vs_oracle(B):
     plans = {"w_1": _plan_of(m, M, di, d, k1), "postnet_mid": _plan_of(m, M, 512, 512, 5), "qkv": _plan_of(m, M, 3 * d, d, 1)}
     nsplit = int(m._lib.ns_plan_attention_split(B, T, t["decoder_head"], d // t["decoder_head"]))
     cut = [k for k, p in plans.items() if p and p["rem"][2] > 0]
-    fine = [k for k, p in plans.items() if p and p["main"][0] % 32 != 0]  # a 16-row-family tile (rows not a multiple of 32)
-    print(f"B={B} T_pad={T} rows={M} plans={plans} attention key split={nsplit}")
+    fine = [k for k, p in plans.items() if p and p["mfma_edge"] == 16]  # a tile of the 16-row family (height chosen for the row count)
+    row_tile = int(m._lib.ns_plan_row_tile(M, d))  # the full-row (GEMM + LayerNorm epilogue) tile's height
+    print(f"B={B} T_pad={T} rows={M} plans={plans} full-row tile {row_tile} attention key split={nsplit}")
+    if row_tile != 32:
+        fine.append("full_row")
     assert plans["w_1"] is not None, "B*T is inside the planner's range"
     assert cut or fine or nsplit > 1, (B, "neither a main + remainder cut, a 16-row tile nor a key split is planned at this shape", plans, nsplit)
     r = _pinned_vs_oracle(m, w, cfg, inp, ref, f"planner shape B={B}")
