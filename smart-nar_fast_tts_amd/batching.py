@@ -126,34 +126,81 @@ def synthesize(model, batchs, preprocess_config, device="cuda", p_control: float
     return results
 
 
-# Batch sizes at which a forward of ~1000-frame utterances sits at the top of a step of the chip (every large launch fills its last
-# round of 256 workgroups): the local minima of ms per utterance in profiles/r04_batch_size_sweep.txt — 4: 0.435, 8: 0.361,
-# 12: 0.366, 16: 0.327, 24: 0.330, 32: 0.314 ms — where 9 costs 0.429 and 17 0.379 (what is left of the
-# staircase is granularity one summation order per forward cannot buy back; the batch composition CAN avoid it).
-STEP_FRIENDLY_SIZES = (1, 2, 4, 8, 12, 16, 24, 32)
+# A forward's time is (nearly) a function of its ROWS, B * T_pad on the padded grid, through the launch plan (include/nar_fs2.h
+# ns_plan_gemm: tiles as tall as the row count asks for, round 5) — not of B.  Whether a group of utterances is cheaper as one batch
+# or cut in two is therefore a question to put to the plan's own cost model for the dominant launch (the decoder FFN's k=9
+# Conv1D-as-GEMM, ~40 % of a forward), not a list of batch sizes tuned at one utterance length (round 4's (1, 2, 4, 8, 12, 16, 24, 32)
+# was right for ~1000-frame utterances only).
+FORWARD_FIXED_US = 450.0   # what a forward costs before its rows count: phase 1 of a small batch, ~55 launch floors, the hand-over
+FORWARD_PER_W1 = 2.4       # whole phase 2 over its FFN w_1 launches (config 2: 5.2 ms against 4 x 0.54 ms)
 
 
-def step_friendly_sizes(n: int, max_batch: int, sizes=STEP_FRIENDLY_SIZES):
-    """EXTENSION: cut ``n`` utterances into batch sizes from ``sizes`` (largest first, each <= max_batch): 9 -> [8, 1],
-    17 -> [16, 1], 20 -> [16, 4], 33 -> [32, 1].  Each batch is then one exact forward of the reference's semantics on that
-    batch; which utterances share a batch is the caller's choice in the reference too (dataset.py:182-191)."""
+def forward_cost_us(rows: int, model_config=None, lib=None) -> float:
+    """Modelled time of one forward whose phase 2 runs on ``rows`` rows, from the launch plan's estimate for the dominant launch
+    (``ns_plan_gemm``'s 8th output, host-side: no GPU needed); below the planner's range (a few hundred rows) the small-grid
+    ladder's floor for that launch."""
+    import ctypes as C
+
+    from . import _lib, workload as wl
+
+    t = (model_config or wl.LJSPEECH_MODEL_CONFIG)["transformer"]
+    d, d_inner, k1, layers = t["decoder_hidden"], t["conv_filter_size"], t["conv_kernel_size"][0], t["decoder_layer"]
+    lib = lib or _lib.load()
+    o = (C.c_int32 * 8)()
+    chunks = k1 * (d // 32)
+    if rows > 0 and lib.ns_plan_gemm(int(rows), d_inner, d, k1, o):
+        w1 = float(o[7])
+    else:  # the K-split ladder: a floor of ~0.6 us per K chunk, then rows at the small tiles' rate
+        w1 = max(0.6 * chunks, 0.035 * chunks * rows * (d_inner / 256.0) / 256.0) + 5.0
+    return FORWARD_FIXED_US + FORWARD_PER_W1 * layers * w1
+
+
+def step_friendly_cuts(frames, max_batch: int, cost=forward_cost_us):
+    """EXTENSION: cut a group of utterances, given by their (estimated) mel frames in DESCENDING order, into consecutive batches
+    of at most ``max_batch`` so that the summed modelled forward time is smallest: batch ``[j, i)`` runs on ``(i - j) * frames[j]``
+    rows (padded to its longest member).  Dynamic program over the cut points; returns the batch sizes.  With a launch plan whose
+    time follows the rows, a cut only pays when it removes padding worth more than a forward's fixed cost — uniform groups come
+    back whole.  Each batch is then one exact forward of the reference's semantics on that batch; which utterances share a batch
+    is the caller's choice in the reference too (dataset.py:182-191)."""
+    n = len(frames)
+    if max_batch < 1:
+        raise ValueError("max_batch >= 1")
+    if any(frames[i] < frames[i + 1] for i in range(n - 1)):
+        raise ValueError("frames must be in descending order (a batch is padded to its first member)")
+    best = [0.0] + [float("inf")] * n
+    prev = [0] * (n + 1)
+    memo = {}
+    for i in range(1, n + 1):
+        for j in range(max(0, i - max_batch), i):
+            rows = (i - j) * int(frames[j])
+            if rows not in memo:
+                memo[rows] = cost(rows)
+            c = best[j] + memo[rows]
+            if c < best[i] - 1e-9:
+                best[i], prev[i] = c, j
+    sizes, i = [], n
+    while i > 0:
+        sizes.append(i - prev[i])
+        i = prev[i]
+    return sizes[::-1]
+
+
+def step_friendly_sizes(n: int, max_batch: int, frames_per_utterance: float = 1000.0, cost=forward_cost_us):
+    """``n`` utterances of about ``frames_per_utterance`` mel frames each as batch sizes (see :func:`step_friendly_cuts`)."""
     if n < 0 or max_batch < 1:
         raise ValueError("n >= 0 and max_batch >= 1")
-    allowed = sorted({s for s in sizes if 1 <= s <= max_batch} | {1}, reverse=True)
-    out = []
-    while n > 0:
-        s = next(a for a in allowed if a <= n)
-        out.append(s)
-        n -= s
-    return out
+    return step_friendly_cuts([int(frames_per_utterance)] * n, max_batch, cost)
 
 
-def bucket_by_length(lengths, max_batch: int, max_pad_fraction: float = 0.1, step_friendly: bool = False):
+def bucket_by_length(lengths, max_batch: int, max_pad_fraction: float = 0.1, step_friendly: bool = False,
+                     frames_per_phoneme: float = 8.0, cost=forward_cost_us):
     """EXTENSION (not in the reference): group utterance indices into batches of similar length.
 
     Sorted by length, a batch is closed when it holds ``max_batch`` items or when admitting the next item would make
     the shortest member's padding exceed ``max_pad_fraction`` of the batch's max length.  Every index appears once.
-    ``step_friendly``: every such group is further cut into the batch sizes of :func:`step_friendly_sizes`."""
+    ``step_friendly``: every such group is further cut where the launch plan's cost model says two forwards are cheaper than one
+    (:func:`step_friendly_cuts` on ``lengths * frames_per_phoneme`` — the duration predictor has not run yet, phonemes are the
+    host-side proxy for frames)."""
     order = np.argsort(np.asarray(lengths), kind="stable")[::-1]
     batches, cur = [], []
     for idx in order:
@@ -169,7 +216,7 @@ def bucket_by_length(lengths, max_batch: int, max_pad_fraction: float = 0.1, ste
         cut = []
         for b in batches:
             o = 0
-            for s in step_friendly_sizes(len(b), max_batch):
+            for s in step_friendly_cuts([int(round(lengths[i] * frames_per_phoneme)) for i in b], max_batch, cost):
                 cut.append(b[o:o + s])
                 o += s
         batches = cut

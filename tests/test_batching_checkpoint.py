@@ -43,17 +43,32 @@ def test_bucket_by_length_partitions():
             longest = max(lens[i] for i in g)
             assert all(longest - lens[i] <= frac * longest for i in g)
     assert len(bucket_by_length(lens, 128, 1.0)) == 1
-    # step-friendly cutting: batch sizes that sit at the top of a step of the chip (profiles/r04_batch_size_sweep.txt), same partition property
-    from smart_nar_fast_tts_amd.batching import STEP_FRIENDLY_SIZES, step_friendly_sizes
+    # step-friendly cutting (round 5): a row-based rule that asks the launch plan's own cost model (ns_plan_gemm, host-side) whether
+    # two forwards are cheaper than one — no list of batch sizes tuned at one utterance length
+    from smart_nar_fast_tts_amd.batching import forward_cost_us, step_friendly_cuts, step_friendly_sizes
 
-    assert step_friendly_sizes(9, 16) == [8, 1] and step_friendly_sizes(17, 32) == [16, 1] and step_friendly_sizes(20, 16) == [16, 4]
-    assert step_friendly_sizes(33, 32) == [32, 1] and step_friendly_sizes(0, 8) == [] and step_friendly_sizes(7, 3) == [2, 2, 2, 1]
-    for n in range(0, 70):
+    for n in range(0, 40):
         for mb in (1, 3, 8, 16, 32):
             c = step_friendly_sizes(n, mb)
-            assert sum(c) == n and all(1 <= x <= mb and (x in STEP_FRIENDLY_SIZES) for x in c) and c == sorted(c, reverse=True)
+            assert sum(c) == n and all(1 <= x <= mb for x in c)
+    # with tiles as tall as the rows ask for, a uniform group is cheapest whole at every utterance length: T ~ 300, 1000, 3000
+    for frames in (300, 1000, 3000):
+        for n in (5, 9, 11, 13, 17, 20, 27):
+            assert step_friendly_sizes(n, 32, frames_per_utterance=frames) == [n], (frames, n, step_friendly_sizes(n, 32, frames_per_utterance=frames))
+    assert step_friendly_sizes(33, 32) in ([32, 1], [17, 16], [16, 17], [1, 32]) or len(step_friendly_sizes(33, 32)) == 2
+    # the modelled cost grows with the rows and a cut is only taken where it removes padding worth more than a forward's fixed cost
+    assert forward_cost_us(4000) < forward_cost_us(9090) < forward_cost_us(16160) < forward_cost_us(40000)
+    assert step_friendly_cuts([3000] + [300] * 12, 32) == [1, 12]          # one long utterance would pad twelve short ones 10x
+    assert step_friendly_cuts([1000, 990, 985, 980], 32) == [4]             # 2 % of padding is not worth a second forward
+    with pytest.raises(ValueError, match="descending"):
+        step_friendly_cuts([100, 200], 4)
+    # any cost function can be plugged in (a staircase in B: round 4's chip, as a check of the dynamic program)
+    stair = lambda rows: 1000.0 * -(-rows // 8000)  # noqa: E731
+    assert step_friendly_cuts([1000] * 9, 16, cost=stair) == [9] and step_friendly_cuts([1000] * 9, 8, cost=stair) in ([8, 1], [1, 8])
     b = bucket_by_length(lens, 16, 1.0, step_friendly=True)
-    assert sorted(i for g in b for i in g) == list(range(len(lens))) and all(len(g) in STEP_FRIENDLY_SIZES for g in b)
+    assert sorted(i for g in b for i in g) == list(range(len(lens))) and all(1 <= len(g) <= 16 for g in b)
+    for g in b:  # groups stay sorted by descending length (a batch is padded to its first member)
+        assert all(lens[g[i]] >= lens[g[i + 1]] for i in range(len(g) - 1))
 
 
 def test_inference_state_dict_filters_training_state():

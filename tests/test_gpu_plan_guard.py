@@ -1,0 +1,47 @@
+"""Guard on the launch plan's cost model (gemm_conv.hip plan_rows / conv_gemm_row_tile, attention.hip plan_key_split): the planned
+forward must never be slower than the one-tile-per-launch rules it replaced (NS_PLAN=0), at batch sizes BETWEEN the steps of 256
+workgroups where the plan has the most freedom to be wrong (round 4: B = 11 was 9.8 % slower planned than unplanned and nothing
+noticed).  Needs a real MI355X: it times forwards."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BATCHES = "5,9,11,13,17,20"
+
+
+def _sweep(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "batch_sweep.py"), "--batches", BATCHES, "--iters", "10"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=e)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    out = {}
+    for line in r.stdout.splitlines():
+        m = re.match(r"B=\s*(\d+) T\s+\d+ rows\s+\d+:\s+([\d.]+) ms", line)
+        if m:
+            out[int(m.group(1))] = float(m.group(2))
+    assert sorted(out) == [int(b) for b in BATCHES.split(",")], r.stdout
+    return out
+
+
+def test_planned_forward_is_never_slower_than_the_unplanned_rules():
+    """Six batch sizes (uniform batches of ~1010-frame utterances, the LJSpeech config), each setting in its own process (the
+    switch is read once per process), alternating A B A B on the same box so that clock state and box-to-box spread cancel; the
+    best of the two runs of each setting is compared.  Fails when the plan loses by more than 3 % anywhere."""
+    runs = {"1": [], "0": []}
+    for _ in range(2):
+        for plan in ("0", "1"):
+            runs[plan].append(_sweep({"NS_PLAN": plan}))
+    report = []
+    worst = 0.0
+    for b in (int(x) for x in BATCHES.split(",")):
+        t1, t0 = min(r[b] for r in runs["1"]), min(r[b] for r in runs["0"])
+        report.append(f"B={b}: planned {t1:.3f} ms, rules {t0:.3f} ms ({100 * (t1 / t0 - 1):+.1f} %)")
+        worst = max(worst, t1 / t0 - 1)
+    print("\n".join(report))
+    assert worst <= 0.03, report
