@@ -740,7 +740,11 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
       // at every row count beyond the small-grid ladder's 32x64 rung: 32 rows x 96 columns with four K groups, one workgroup
       // per CU (tools/lab/gemm_lab_n80b.hip, k5 512->80, us: M = 5050 46.9 (32x128 KS2) -> 36.8, 9090 87.1 -> 72.4,
       // 12120 84.9 -> 71.1, 32480 158.5 (64x96) -> 140.9; below M ~ 4100 the ladder wins, 29.1 vs 37.2)
-      if (wgs(rows32, 64) > 256) return launch_t<32, 96, 32, 4, 1, 3>(p, st, tm);
+      if (wgs(rows32, 64) > 256) {
+        // between one and two rounds of that tile (B = 9 ... 12 utterances: 285 workgroups took as long as 512): 48 rows tall, one round
+        if (tile16_enabled() && rows32 > 256 && (p.M + 47) / 48 <= 256) return launch_t<48, 96, 32, 4, 1, 3, false, 0, 16>(p, st, tm);
+        return launch_t<32, 96, 32, 4, 1, 3>(p, st, tm);
+      }
     } else {
       if (rows64 >= 512) return launch_t<64, 96, 32, 1, 2, 3>(p, st, tm);
       if (rows32 >= 400) return launch_t<32, 96, 32, 4, 1, 3>(p, st, tm);
