@@ -802,10 +802,16 @@ static int forward_durations(ns_model* m, const int64_t* texts, const int64_t* s
     // Phase-1 launches are small grids: their time is steps of 256 workgroups x a K loop, not rows (measured, config-2 shape with
     // 0.66 of the rows: 4.32 ms packed vs 4.29 ms on the grid — the same two steps everywhere, plus the plan / unpack / attention-merge
     // launches).  So pack only when the rows drop by a whole step of the launch that dominates the phase, the FFN k=9 GEMM on
-    // 32x128 tiles (4 x ~38 us per step saved against ~50 us of extra launches), and by at least 10 %.
+    // 32x128 tiles (4 x ~38 us per step saved against ~50 us of extra launches) — or from two steps to one of its 48-row form
+    // (4 x ~18 us) — and by at least 10 %.
     Mp = phase1_packed_rows(lens_host, B, L);
-    auto steps = [&](size_t rows) { return ((rows + 31) / 32 * ((size_t)c.d_inner / 128) + 255) / 256; };
-    packed = Mp > 0 && Mp * 10 <= (size_t)B * L * 9 && (c.phase1_packing == 1 || steps(Mp) < steps((size_t)B * L));
+    // rows the fullest CU gets from that launch on the small-grid ladder: rounds of the 32 x 128 rung, or — round 5 — ONE round of its
+    // 48-row form when that fits (the ragged config-2 shape: 1388 packed rows = 232 workgroups of 48 rows against 512 of 32 on the grid)
+    auto cu_rows = [&](size_t rows) {
+      const size_t ntn = (size_t)c.d_inner / 128, w32 = (rows + 31) / 32 * ntn, w48 = (rows + 47) / 48 * ntn;
+      return (w32 > 256 && w48 <= 256) ? (size_t)48 : 32 * ((w32 + 255) / 256);
+    };
+    packed = Mp > 0 && Mp * 10 <= (size_t)B * L * 9 && (c.phase1_packing == 1 || cu_rows(Mp) < cu_rows((size_t)B * L));
   }
   const size_t Mrows = packed ? Mp : (size_t)B * L;
   m->last_rows1 = (long long)Mrows;

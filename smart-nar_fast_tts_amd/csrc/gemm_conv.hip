@@ -622,18 +622,25 @@ static RowPlan plan_rows(long M, int N, int chunks) {
       }
     }
   }
-  // the 16-row family: one launch, the tile height chosen for the row count.  It has to beat the 32-row plans by 3 % (between
-  // near-ties the plans that forward A/B runs settled at the BASELINE configurations stay: with the family allowed everywhere
-  // configs 2 / 4 / 5 measured 5.21-5.32 / 55.93-55.95 / 12.18-12.19 ms against 5.23 / 55.91-55.93 / 12.16-12.17 without it)
+  // the 16-row family: one launch, the tile height chosen for the row count.  Where the best 32-row plan is ONE launch that fills its
+  // steps (>= 90 %) the family has to beat it by 3 %: between near-ties the plans that forward A/B runs settled at the BASELINE
+  // configurations stay (with the family allowed everywhere configs 2 / 4 / 5 measured 5.21-5.32 / 55.93-55.95 / 12.18-12.19 ms
+  // against 5.23 / 55.91-55.93 / 12.16-12.17 without it).  Against a cut plan or badly filled steps: 1 %.
   if (tile16_enabled()) {
+    float margin = 1.01f;
+    if (best.main_rows == 0 && best.rem.fam == F32) {
+      const long w = tile_wgs(best.rem.id, M, N);
+      const long slots = 256 * (best.rem.id == T64W ? 2 : best.rem.id == T64 ? 3 : best.rem.id >= T64N ? 4 : 1);  // co-resident workgroups per CU
+      if ((double)w / (double)(((w + slots - 1) / slots) * slots) >= 0.9) margin = 1.03f;
+    }
     if (N % 256 == 0)
       for (int sl = F16W_MIN; sl <= F16W_MAX; ++sl) {
-        const float c = tile16_time(F16W, sl, M, N, chunks) * 1.03f;
+        const float c = tile16_time(F16W, sl, M, N, chunks) * margin;
         if (c < best.us) best = RowPlan{{F32, -1}, 0, {F16W, sl}, c};
       }
     if (N % 128 == 0)
       for (int sl = F16N_MIN; sl <= F16N_MAX; ++sl) {
-        const float c = tile16_time(F16N, sl, M, N, chunks) * 1.03f;
+        const float c = tile16_time(F16N, sl, M, N, chunks) * margin;
         if (c < best.us) best = RowPlan{{F32, -1}, 0, {F16N, sl}, c};
       }
   }
