@@ -831,6 +831,11 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
     const int nch = p.KW * (p.Cin / 32);
     if (wgs(rows32, 32) <= 256) return nch >= 16 ? launch_t<32, 32, 32, 8, 1, 1>(p, st, tm) : launch_t<32, 32, 32, 4, 1, 1>(p, st, tm);
     if (wgs(rows32, 64) <= 256) return launch_t<32, 64, 32, 4, 1, 2>(p, st, tm);
+    // a long-K GEMM on about one workgroup per CU (the single utterance's decoder FFN: M = 788, k9 256->1024): the same outputs per CU
+    // as 32 x 128 from a SQUARE 64 x 64 tile on 16 waves (four K groups) pull (64 + 64) instead of (32 + 128) operand rows through
+    // LDS-DMA, which is what bounds these launches (round 3): 47.5 -> 44.9 us (tools/lab/gemm_lab_r5b.hip)
+    if (launch_planner_enabled() && tile16_enabled() && nch >= 32 && wgs(rows32, 128) <= 256 && wgs(rows64, 64) >= 160 && wgs(rows64, 64) <= 256)
+      return launch_t<64, 64, 32, 4, 2, 2>(p, st, tm);
     if (wgs(rows32, 128) <= 512) {
       // between one and two rounds of the 32x128 rung (B = 9 ... 12 encoder grids: 288 workgroups took as long as 512): the same
       // rung 48 rows tall, one round (16-row family; tools/lab/gemm_lab_mf16.hip, k9 256->1024: M = 1152 80.5 -> 63.1 us, 1408 79.6 -> 63.9)

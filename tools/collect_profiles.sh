@@ -9,7 +9,7 @@
 # MI355X_MICROARCH.md prescribes).  bench.py runs with --no-extras under the profiler: the trace then holds exactly
 # (warmup + steps) forwards of the workload, nothing else.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
@@ -38,8 +38,14 @@ python "$ROOT/tools/batch_sweep.py" > "$OUT/${R}_batch_size_sweep.txt" 2> "$OUT/
 NS_PLAN=0 python "$ROOT/tools/batch_sweep.py" > "$OUT/${R}_batch_size_sweep_plan0.txt" 2>> "$OUT/${R}_batch_size_sweep.err"
 python "$ROOT/tools/batch_sweep.py" --ragged --batches 4,8,12,16,24,32 > "$OUT/${R}_batch_size_sweep_ragged.txt" 2>> "$OUT/${R}_batch_size_sweep.err"
 NS_PACKED=0 python "$ROOT/tools/batch_sweep.py" --ragged --batches 4,8,12,16,24,32 > "$OUT/${R}_batch_size_sweep_ragged_grid.txt" 2>> "$OUT/${R}_batch_size_sweep.err"
-# per-launch view of two batch sizes that sit between steps (B = 9, B = 20)
-bash "$ROOT/tools/trace_batches.sh" ${R}_tb 9 20 > "$OUT/${R}_tb.log" 2>&1
+# per-launch view of batch sizes that sit between steps (B = 9, 17, 20)
+bash "$ROOT/tools/trace_batches.sh" ${R}_tb 9 17 20 > "$OUT/${R}_tb.log" 2>&1
+# the 16-row tile family off / on, alternating processes on this box (round 5): uniform batches B = 4 ... 32, ragged batches
+( cd "$ROOT" && tools/ab_sweep.sh "$OUT/${R}_ab_tile16" "NS_TILE16=0" "NS_TILE16=1" > "$OUT/${R}_ab_tile16.txt" 2>&1 )
+( cd "$ROOT" && tools/ab_sweep.sh "$OUT/${R}_ab_tile16_ragged" "NS_TILE16=0" "NS_TILE16=1" 4,8,9,12,16,20,24,32 --ragged > "$OUT/${R}_ab_tile16_ragged.txt" 2>&1 )
+# phase 1 on packed phoneme rows against the grid (ragged batches, src_lens on the host)
+python "$ROOT/tools/phase1_packing_ab.py" > "$OUT/${R}_phase1_packing_ab.txt" 2>&1
+cd /tmp
 # rocprofv3's own per-kernel summary of the config-2 run, as it wrote it
 find "$OUT/${R}_trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/${R}_rocprofv3_kernel_stats.csv" \;
 

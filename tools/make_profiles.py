@@ -116,12 +116,13 @@ if lp:
 json.dump({"bench": bench, "bench_under_kernel_trace": under}, open(f"profiles/{ROUND}_bench.json", "w"), indent=1)
 
 # the other BASELINE configs (kernel trace only) and the opt-in bf16x3 mode
-for fn in ("batch_size_sweep", "batch_size_sweep_plan0", "batch_size_sweep_ragged", "batch_size_sweep_ragged_grid", "fuzz"):
+for fn in ("batch_size_sweep", "batch_size_sweep_plan0", "batch_size_sweep_ragged", "batch_size_sweep_ragged_grid", "fuzz",
+           "ab_tile16", "ab_tile16_ragged", "phase1_packing_ab"):
     src = f"{G}/{ROUND}_{fn}.txt"
     if os.path.exists(src):
         txt = "".join(l for l in open(src) if "amdgpu.ids" not in l)
         open(f"profiles/{ROUND}_{fn}.txt", "w").write(txt)
-for b in (9, 20):  # per-launch sequences of two batch sizes that sit between steps
+for b in (9, 17, 20):  # per-launch sequences of batch sizes that sit between steps
     src = f"{G}/{ROUND}_tb_b{b}.seq.txt"
     if os.path.exists(src):
         shutil.copy(src, f"profiles/{ROUND}_launch_sequence_b{b}.txt")
