@@ -549,8 +549,15 @@ static bool tile16_enabled() {  // NS_TILE16=0: the planner without the 16-row f
   static const bool on = [] { const char* e = getenv("NS_TILE16"); return !(e && e[0] == '0'); }();
   return on;
 }
+static bool tile16n_enabled() {  // NS_TILE16N=0: the family without its 128-column form (A/B runs; read once)
+  static const bool on = [] { const char* e = getenv("NS_TILE16N"); return !(e && e[0] == '0'); }();
+  return on;
+}
 // per-CU rows of a launch of `wgs` equal workgroups (the dispatcher hands a CU its next workgroup when a slot frees; co-resident
-// workgroups share the CU's matrix pipe, so what counts is how many land on the fullest CU) times the per-row, per-chunk rate
+// workgroups share the CU's matrix pipe, so what counts is how many land on the fullest CU) times the per-row, per-chunk rate.
+// The ramp + drain is charged per 256 workgroups although co-resident workgroups overlap theirs: many small workgroups per CU each
+// stream their own weight panel ((BM + BN) operand rows per BM x BN outputs), and the charge stands in for that — with it the
+// model ranks 48 x 256 x 3 per CU 3 % behind 144 x 256 x 1 as the lab does (369 vs 357 us); without it the plan drifts to the small tiles.
 static float tile16_time(int fam, int slabs, long M, int N, int chunks) {
   const int bm = 16 * slabs, bn = fam == F16W ? 256 : 128;
   const long wgs = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
@@ -638,7 +645,7 @@ static RowPlan plan_rows(long M, int N, int chunks) {
         const float c = tile16_time(F16W, sl, M, N, chunks) * margin;
         if (c < best.us) best = RowPlan{{F32, -1}, 0, {F16W, sl}, c};
       }
-    if (N % 128 == 0)
+    if (N % 128 == 0 && tile16n_enabled())
       for (int sl = F16N_MIN; sl <= F16N_MAX; ++sl) {
         const float c = tile16_time(F16N, sl, M, N, chunks) * margin;
         if (c < best.us) best = RowPlan{{F32, -1}, 0, {F16N, sl}, c};
@@ -831,11 +838,9 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
     const int nch = p.KW * (p.Cin / 32);
     if (wgs(rows32, 32) <= 256) return nch >= 16 ? launch_t<32, 32, 32, 8, 1, 1>(p, st, tm) : launch_t<32, 32, 32, 4, 1, 1>(p, st, tm);
     if (wgs(rows32, 64) <= 256) return launch_t<32, 64, 32, 4, 1, 2>(p, st, tm);
-    // a long-K GEMM on about one workgroup per CU (the single utterance's decoder FFN: M = 788, k9 256->1024): the same outputs per CU
-    // as 32 x 128 from a SQUARE 64 x 64 tile on 16 waves (four K groups) pull (64 + 64) instead of (32 + 128) operand rows through
-    // LDS-DMA, which is what bounds these launches (round 3): 47.5 -> 44.9 us (tools/lab/gemm_lab_r5b.hip)
-    if (launch_planner_enabled() && tile16_enabled() && nch >= 32 && wgs(rows32, 128) <= 256 && wgs(rows64, 64) >= 160 && wgs(rows64, 64) <= 256)
-      return launch_t<64, 64, 32, 4, 2, 2>(p, st, tm);
+    // (a square 64 x 64 KS4 tile on 16 waves for long-K launches of about one workgroup per CU — (64 + 64) operand rows per CU instead of
+    //  (32 + 128) — measured 47.5 -> 44.9 us in the lab at M = 788 and nothing in the forward: single utterance 0.8443 / 0.8419 ms without,
+    //  0.8421 / 0.8408 with, alternating runs; not taken.  tools/lab/gemm_lab_r5b.hip)
     if (wgs(rows32, 128) <= 512) {
       // between one and two rounds of the 32x128 rung (B = 9 ... 12 encoder grids: 288 workgroups took as long as 512): the same
       // rung 48 rows tall, one round (16-row family; tools/lab/gemm_lab_mf16.hip, k9 256->1024: M = 1152 80.5 -> 63.1 us, 1408 79.6 -> 63.9)
