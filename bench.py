@@ -274,6 +274,8 @@ def main():
                     help="profiling runs: only warm-up + timed steps (no latency leg, no pipelined leg, no CPU baseline), so that a "
                          "kernel trace holds exactly (warmup + steps) forwards of the workload")
     ap.add_argument("--ragged", action="store_true", help="ragged utterance lengths instead of the uniform BASELINE batch (phase 2 then runs on packed rows; NS_PACKED=0 keeps the padded grid)")
+    ap.add_argument("--host-lens", action="store_true", help="hand src_lens to forward() as a HOST tensor (what a caller that collates on the host holds): "
+                    "phase 1 of a ragged batch may then run on packed phoneme rows too (traces of that path)")
     ap.add_argument("--batch", type=int, default=0, help="override the workload's per-GPU batch size (sweeps; not a BASELINE config)")
     ap.add_argument("--streams", type=int, default=1, help="issue consecutive steps round-robin on this many HIP streams")
     ap.add_argument("--global-pad", action="store_true", help="pad every shard to the global max mel length (all-reduce MAX)")
@@ -364,6 +366,8 @@ def main():
     shard_phonemes = [int(np.asarray(ln)[p].sum()) for p in sharding.shard_indices(ln, world, balance)]
     sp, tx, ln, Lmax = sharding.shard_batch(sp, tx, ln, world, rank, balance=balance)
     speakers, texts, src_lens = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (sp, tx, ln))
+    if args.host_lens:
+        src_lens = torch.from_numpy(np.ascontiguousarray(ln))
     pad_fn = sharding.global_max if (args.global_pad and world > 1) else None
 
     # --streams S > 1: consecutive steps go round-robin onto S HIP streams, so the small-grid phase 1 of step i+1 (and

@@ -613,7 +613,7 @@ static int mha(ns_model* m, const LayerW& L, int d, int H, const float* x, const
     ProfScope ps(m, 1, 4.0 * (double)M * (double)S * (double)d);
     NS_TRY(ps.begin());
     NS_HIP(launch_attention(sc.qkv, lens, B, S, H, d / H, sc.att, sc.att_part, sc.att_part_floats,
-                            (sc.att_part && !sc.pk && attention_uses_tickets(B, S, H)) ? sc.take_tickets(attention_ticket_ints(B, S, H)) : nullptr, st, cur_rm(sc),
+                            (sc.att_part && attention_uses_tickets(B, S, H)) ? sc.take_tickets(attention_ticket_ints(B, S, H)) : nullptr, st, cur_rm(sc),
                             ps.timing()));
     ps.end();
   }

@@ -346,9 +346,10 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
 // i in key order — exact for any split (each partial is an exact softmax numerator / denominator relative to its own m_i).
 template <int DK>
 __global__ __launch_bounds__(256) void k_attention_strip(const float* __restrict__ qkv, const long long* __restrict__ lens,
-                                                          int S, int d, float c_scale, float* __restrict__ out, int nsplit,
+                                                          int S_grid, int d, float c_scale, float* __restrict__ out, int nsplit,
                                                           float* __restrict__ opart, float* __restrict__ mlpart,
-                                                          int* __restrict__ tickets) {
+                                                          int* __restrict__ tickets, const int* __restrict__ pk_off,
+                                                          const int* __restrict__ pk_win, int pk_rows) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BC = 32, CPR = DK / 4, RPI = 64 / CPR;
   constexpr int NI = (BC * CPR) / 64;  // DMA instructions per tile: ONE wave fills its own tile
@@ -367,9 +368,14 @@ __global__ __launch_bounds__(256) void k_attention_strip(const float* __restrict
   const int nstrips = gridDim.x / nsplit;
   const int strip = blockIdx.x / nsplit, sp = blockIdx.x - strip * nsplit;
   const int hd = blockIdx.y, b = blockIdx.z;
+  // packed rows (kernels.h RowMap): utterance b owns rows [pk_off[b], pk_off[b] + pk_win[b]) of the pk_rows packed rows; the grid is
+  // sized for the longest window (S_grid), a strip past this utterance's window has nothing to do (no barrier was reached yet)
+  const int row0 = pk_off ? pk_off[b] : b * S_grid;
+  const int S = pk_off ? pk_win[b] : S_grid;
+  if (strip * 32 >= S) return;
   const int q = strip * 32 + qi;
   const int ld = 3 * d;
-  const float* base = qkv + (size_t)b * S * ld + hd * DK;
+  const float* base = qkv + (size_t)row0 * ld + hd * DK;
   const long long len_ll = lens ? lens[b] : (long long)S;
   const int len = (int)(len_ll < S ? len_ll : S);
   const int nkt_all = (len + BC - 1) / BC;
@@ -538,19 +544,19 @@ __global__ __launch_bounds__(256) void k_attention_strip(const float* __restrict
     }
   };
   if (nsplit == 1) {
-    if (q < S) pieces(1.0f / l_all, out + ((size_t)b * S + q) * d + hd * DK + 4 * h);  // lens[b]==0 -> 0 * inf = NaN, as the reference
+    if (q < S) pieces(1.0f / l_all, out + ((size_t)row0 + q) * d + hd * DK + 4 * h);  // lens[b]==0 -> 0 * inf = NaN, as the reference
     return;
   }
   // ---- several workgroups share this strip: publish the un-normalised partial, the last arriver merges in split order.
   // Partials travel as 16-byte write-through (sc1) stores and are read back with sc1 loads — all splits' loads in flight at
   // once — so neither side needs a cache write-back / invalidate fence.
-  const size_t Mrows = (size_t)gridDim.z * S;
+  const size_t Mrows = pk_off ? (size_t)pk_rows : (size_t)gridDim.z * S;
   const int H = gridDim.y;
   const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)opart, (short)0, 0x7FFFFFFF, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsML = __builtin_amdgcn_make_buffer_rsrc((void*)mlpart, (short)0, 0x7FFFFFFF, 0x00020000);
   const int qc = q < S ? q : S - 1;  // rows past S: read / write nothing that matters (stores are predicated)
-  auto orow = [&](int s2) { return (int)((((size_t)s2 * Mrows + (size_t)b * S + qc) * d + hd * DK + 4 * h + 8 * NDB * u) * 4); };
-  auto mlrow = [&](int s2) { return (int)(((((size_t)s2 * Mrows + (size_t)b * S + qc) * H + hd) * 2) * 4); };
+  auto orow = [&](int s2) { return (int)((((size_t)s2 * Mrows + (size_t)row0 + qc) * d + hd * DK + 4 * h + 8 * NDB * u) * 4); };
+  auto mlrow = [&](int s2) { return (int)(((((size_t)s2 * Mrows + (size_t)row0 + qc) * H + hd) * 2) * 4); };
   if (q < S) {
 #pragma unroll
     for (int pj = 0; pj < NDB; ++pj) {
@@ -604,7 +610,7 @@ __global__ __launch_bounds__(256) void k_attention_strip(const float* __restrict
   }
   if (q >= S) return;
   const float inv = 1.0f / l;
-  float* dst = out + ((size_t)b * S + q) * d + hd * DK + 4 * h + 8 * NDB * u;
+  float* dst = out + ((size_t)row0 + q) * d + hd * DK + 4 * h + 8 * NDB * u;
 #pragma unroll
   for (int pj = 0; pj < NDB; ++pj) *reinterpret_cast<f32x4*>(dst + 8 * pj) = acc[pj] * inv;
 #endif
@@ -697,6 +703,46 @@ static void launch_k_attention(dim3 grid, hipStream_t st, hipEvent_t e0, hipEven
   else hipLaunchKernelGGL((k_attention<DK>), grid, dim3(256), 0, st, args...);
 }
 
+// Few workgroups (single-utterance latency, the encoder): a 128-query workgroup's time is its serial sweep over the key tiles.
+// First choice, k_attention_strip: a workgroup per 32-query strip whose four waves split the key axis, and up to nsplit such
+// workgroups per strip merged by the last arriver — taken when that leaves every wave at most 4 key tiles (beyond that the shared
+// K / V tiles of k_attention win: a strip's waves each pull their own).  rm != nullptr: packed rows (kernels.h RowMap; round 5 — phase 1
+// of a ragged batch on packed phoneme rows used k_attention + k_attention_merge, one launch more per layer): the grid is sized
+// for the longest window S, every utterance's strips address its own rows.  false = not taken (the caller's other paths).
+static bool launch_strips(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, float* scratch, size_t scratch_floats,
+                          int* tickets, hipStream_t st, const RowMap* rm, hipEvent_t ev0, hipEvent_t ev1) {
+  const int d = H * dk, tiles = (S + 31) / 32;
+  const float c = 1.4426950408889634f / sqrtf((float)dk);
+  const size_t M = rm ? (size_t)rm->rows : (size_t)B * S;
+  auto part_floats = [&](int n) { return (size_t)n * (M * d + 2 * M * H); };
+  const long strips = (long)tiles * H * B;
+  int nsplit = (int)((256 + strips - 1) / strips);
+  if (nsplit > (tiles + 3) / 4) nsplit = (tiles + 3) / 4;   // at least one key tile per wave
+  if (nsplit > ATT_STRIP_SPLIT_MAX) nsplit = ATT_STRIP_SPLIT_MAX;
+  if (nsplit > 1 && !scratch) nsplit = 1;
+  if (part_floats(nsplit) * 4 >= (1ull << 31)) nsplit = 1;  // 31-bit descriptor offsets over the partials
+  while (nsplit > 1 && part_floats(nsplit) > scratch_floats) --nsplit;
+  int tpr = (tiles + 4 * nsplit - 1) / (4 * nsplit);
+  nsplit = ((tiles + tpr - 1) / tpr + 3) / 4;                // no workgroup of empty ranges
+  tpr = (tiles + 4 * nsplit - 1) / (4 * nsplit);
+  if (tpr > 4) return false;
+  float* opart = nsplit > 1 ? scratch : nullptr;
+  float* mlpart = nsplit > 1 ? scratch + (size_t)nsplit * M * d : nullptr;
+  const int* off = rm ? rm->off : nullptr;
+  const int* win = rm ? rm->win : nullptr;
+  const int rows = rm ? rm->rows : 0;
+  dim3 grid(tiles * nsplit, H, B), block(256);
+  if (ev0) (void)hipEventRecord(ev0, st);  // (small-grid path: plain marker events, this launch is not a roofline case)
+  if (dk == 128) hipLaunchKernelGGL((k_attention_strip<128>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, tickets, off, win, rows);
+  else if (dk == 64) hipLaunchKernelGGL((k_attention_strip<64>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, tickets, off, win, rows);
+  else hipLaunchKernelGGL((k_attention_strip<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, tickets, off, win, rows);
+  // without a ticket block (ns_config.row_epilogue = two_launch, or the phase's block is spent) the strips' partials are
+  // merged by a launch of their own: same layout, same split order, same arithmetic as the last arriver's merge
+  if (nsplit > 1 && !tickets) hipLaunchKernelGGL(k_attention_merge, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, opart, mlpart, (int)M, d, H, dk, nsplit, out);
+  if (ev1) (void)hipEventRecord(ev1, st);
+  return true;
+}
+
 hipError_t launch_attention(const float* qkv, const long long* lens, int B, int S, int H, int dk, float* out, float* scratch,
                             size_t scratch_floats, int* tickets, hipStream_t st, const RowMap* rm, const LaunchTiming* tm) {
   if (B <= 0 || S <= 0) return hipSuccess;
@@ -705,6 +751,10 @@ hipError_t launch_attention(const float* qkv, const long long* lens, int B, int 
     const int d = H * dk;
     if ((long long)S * 3 * d * 4 >= (1ll << 31) || (dk != 128 && dk != 64 && dk != 32) || !rm->off || !rm->win) return hipErrorInvalidValue;
     if (!rm->att_off || !rm->att_order || rm->att_wgs <= 0 || rm->rows <= 0) return hipErrorInvalidValue;
+    // a handful of short windows (phase 1 of a ragged batch, L <= ~500): the strip kernel on the packed rows, no merge launch
+    if ((long)((S + 127) / 128) * H * B < ATT_SPLIT_MAX_BLOCKS && (long long)rm->rows * 3 * d * 4 < (1ll << 31) &&
+        launch_strips(qkv, lens, B, S, H, dk, out, scratch, scratch_floats, tickets, st, rm, ev0, ev1))
+      return hipGetLastError();
     const float c = 1.4426950408889634f / sqrtf((float)dk);
     // Few workgroups (a handful of ragged utterances): the launch would last as long as the longest utterance's sweep while
     // most CUs idle.  Every workgroup's key axis is cut into nsplit ranges (of ITS utterance's key tiles), the partials are
@@ -739,36 +789,7 @@ hipError_t launch_attention(const float* qkv, const long long* lens, int B, int 
   const long blocks = (long)qtiles * H * B;
   const size_t M = (size_t)B * S;
   auto part_floats = [&](int n) { return (size_t)n * (M * d + 2 * M * H); };
-  if (blocks < ATT_SPLIT_MAX_BLOCKS) {
-    // Few workgroups (single-utterance latency, the encoder): a 128-query workgroup's time is its serial sweep over the
-    // key tiles.  First choice, k_attention_strip: a workgroup per 32-query strip whose four waves split the key axis, and up
-    // to nsplit such workgroups per strip merged by the last arriver — taken when that leaves every wave at most 4 key tiles
-    // (beyond that the shared K / V tiles of k_attention win: a strip's waves each pull their own).
-    const long strips = (long)tiles * H * B;
-    int nsplit = (int)((256 + strips - 1) / strips);
-    if (nsplit > (tiles + 3) / 4) nsplit = (tiles + 3) / 4;   // at least one key tile per wave
-    if (nsplit > ATT_STRIP_SPLIT_MAX) nsplit = ATT_STRIP_SPLIT_MAX;
-    if (nsplit > 1 && !scratch) nsplit = 1;
-    if (part_floats(nsplit) * 4 >= (1ull << 31)) nsplit = 1;  // 31-bit descriptor offsets over the partials
-    while (nsplit > 1 && part_floats(nsplit) > scratch_floats) --nsplit;
-    int tpr = (tiles + 4 * nsplit - 1) / (4 * nsplit);
-    nsplit = ((tiles + tpr - 1) / tpr + 3) / 4;                // no workgroup of empty ranges
-    tpr = (tiles + 4 * nsplit - 1) / (4 * nsplit);
-    if (tpr <= 4) {
-      float* opart = nsplit > 1 ? scratch : nullptr;
-      float* mlpart = nsplit > 1 ? scratch + (size_t)nsplit * M * d : nullptr;
-      dim3 grid(tiles * nsplit, H, B), block(256);
-      if (ev0) (void)hipEventRecord(ev0, st);  // (small-grid path: plain marker events, this launch is not a roofline case)
-      if (dk == 128) hipLaunchKernelGGL((k_attention_strip<128>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, tickets);
-      else if (dk == 64) hipLaunchKernelGGL((k_attention_strip<64>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, tickets);
-      else hipLaunchKernelGGL((k_attention_strip<32>), grid, block, 0, st, qkv, lens, S, d, c, out, nsplit, opart, mlpart, tickets);
-      // without a ticket block (ns_config.row_epilogue = two_launch, or the phase's block is spent) the strips' partials are
-      // merged by a launch of their own: same layout, same split order, same arithmetic as the last arriver's merge
-      if (nsplit > 1 && !tickets) hipLaunchKernelGGL(k_attention_merge, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, opart, mlpart, (int)M, d, H, dk, nsplit, out);
-      if (ev1) (void)hipEventRecord(ev1, st);
-      return hipGetLastError();
-    }
-  }
+  if (blocks < ATT_SPLIT_MAX_BLOCKS && launch_strips(qkv, lens, B, S, H, dk, out, scratch, scratch_floats, tickets, st, nullptr, ev0, ev1)) return hipGetLastError();
   // Otherwise k_attention; still few workgroups (long single utterances): split the key sweep over up to ATT_SPLIT_MAX
   // workgroups per 128-query tile until the launch has ~256 of them, then merge the partials with k_attention_merge.
   // Needs nsplit * (M*d + 2*M*H) floats of scratch.
