@@ -472,7 +472,10 @@ static hipError_t launch_t(const ConvGemm& p, hipStream_t st, const LaunchTiming
 }
 
 bool conv_gemm_ticket_ok(int M, int N, int Cin) {
-  return M > 0 && (N == 256 || N == 512) && Cin % 32 == 0 && (long long)M * N * 4 < (1ll << 31);
+  // ... and few enough tiles for the ladder's K-split rungs (<= 512 workgroups of 32 x 128): beyond that the ladder's last rung was a
+  // plain 64 x 64 tile whose ticketed instantiations spilled 85 / 106 SGPRs (round-4 review) for a range only a 512-wide model
+  // with 4096 < M < 6400 rows ever reached — such launches take the two-launch form (GEMM, then the row kernel) instead
+  return M > 0 && (N == 256 || N == 512) && Cin % 32 == 0 && (long long)M * N * 4 < (1ll << 31) && (long)((M + 31) / 32) * ((N + 127) / 128) <= 512;
 }
 
 bool conv_gemm_row_epilogue_ok(int M, int N, int Cin) {
@@ -709,7 +712,7 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
     if (wgs(rows32, 32) <= 256) return nch >= 16 ? launch_t<32, 32, 32, 8, 1, 1, false, NVT>(p, st, tm) : launch_t<32, 32, 32, 4, 1, 1, false, NVT>(p, st, tm); \
     if (wgs(rows32, 64) <= 256) return launch_t<32, 64, 32, 4, 1, 2, false, NVT>(p, st, tm);                                             \
     if (wgs(rows32, 128) <= 512) return launch_t<32, 128, 32, 2, 1, 4, false, NVT>(p, st, tm);                                           \
-    return launch_t<64, 64, 32, 1, 2, 2, false, NVT>(p, st, tm);
+    return hipErrorInvalidValue; /* (unreachable: conv_gemm_ticket_ok bounds the tile count) */
     if (p.N == 256) { NS_TICKET_LADDER(1) }
     NS_TICKET_LADDER(2)
 #undef NS_TICKET_LADDER

@@ -454,6 +454,14 @@ def test_launch_plan_invariants_and_settled_choices(lib):
     rt = {M: lib.ns_plan_row_tile(M, 256) for M in (8080, 9090, 10490, 11110, 12120, 16160, 17170, 20200, 31248)}
     assert rt == {8080: 32, 9090: 48, 10490: 48, 11110: 48, 12120: 48, 16160: 32, 17170: 80, 20200: 80, 31248: 32}, rt
     assert lib.ns_plan_row_tile(66624, 512) == 32 and lib.ns_plan_row_tile(9090, 512) == 48 and lib.ns_plan_row_tile(9090, 300) == 0
+    # "time follows the rows": the model's cost per utterance for the dominant launch never jumps by more than 6 % from B to B + 1
+    # utterances of 1010 frames (round 4's plans: +19 % at B = 8 -> 9, +16 % at 16 -> 17 in the measured forward), and it is
+    # monotone in the rows up to one microsecond of rounding
+    per = {B: plan(B * 1010, 1024, 256, 9)[1][7] / B for B in range(5, 33)}
+    worst = max(per[B + 1] / per[B] for B in range(5, 32))
+    assert worst <= 1.06, (worst, per)
+    us = [plan(M, 1024, 256, 9)[1][7] for M in range(5000, 33000, 250)]
+    assert all(b >= a - 1 for a, b in zip(us, us[1:])), us
     # below the planner's range: the small-grid K-split ladder (encoder rows, single utterances)
     assert plan(2048, 1024, 256, 9)[0] == 0 and plan(788, 512, 512, 5)[0] == 0 and plan(16160, 80, 512, 5)[0] == 0
     # attention: one workgroup per CU -> a key split only when the last round of 256 fills badly

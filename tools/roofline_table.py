@@ -77,7 +77,7 @@ SPLITTABLE = ("QKV projection", "FFN w_1", "mel_linear", "PostNet conv")
 
 
 def is_plain_gemm(n):
-    return "k_conv_gemm<" in n and re.search(r"false, 0>", n) is not None
+    return "k_conv_gemm<" in n and re.search(r"false, 0(, \d+)?>", n) is not None
 
 
 sys.setrecursionlimit(10000)
