@@ -809,7 +809,7 @@ static int forward_durations(ns_model* m, const int64_t* texts, const int64_t* s
     // 48-row form when that fits (the ragged config-2 shape: 1388 packed rows = 232 workgroups of 48 rows against 512 of 32 on the grid)
     auto cu_rows = [&](size_t rows) {
       const size_t ntn = (size_t)c.d_inner / 128, w32 = (rows + 31) / 32 * ntn, w48 = (rows + 47) / 48 * ntn;
-      return (w32 > 256 && w48 <= 256) ? (size_t)48 : 32 * ((w32 + 255) / 256);
+      return (conv_gemm_tile16_enabled() && w32 > 256 && w48 <= 256) ? (size_t)48 : 32 * ((w32 + 255) / 256);
     };
     packed = Mp > 0 && Mp * 10 <= (size_t)B * L * 9 && (c.phase1_packing == 1 || cu_rows(Mp) < cu_rows((size_t)B * L));
   }

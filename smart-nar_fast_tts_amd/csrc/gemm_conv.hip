@@ -552,6 +552,7 @@ static bool tile16_enabled() {  // NS_TILE16=0: the planner without the 16-row f
   static const bool on = [] { const char* e = getenv("NS_TILE16"); return !(e && e[0] == '0'); }();
   return on;
 }
+bool conv_gemm_tile16_enabled() { return launch_planner_enabled() && tile16_enabled(); }
 static bool tile16n_enabled() {  // NS_TILE16N=0: the family without its 128-column form (A/B runs; read once)
   static const bool on = [] { const char* e = getenv("NS_TILE16N"); return !(e && e[0] == '0'); }();
   return on;
@@ -632,16 +633,16 @@ static RowPlan plan_rows(long M, int N, int chunks) {
       }
     }
   }
-  // the 16-row family: one launch, the tile height chosen for the row count.  Where the best 32-row plan is ONE launch that fills its
-  // steps (>= 90 %) the family has to beat it by 3 %: between near-ties the plans that forward A/B runs settled at the BASELINE
+  // the 16-row family: one launch, the tile height chosen for the row count.  Where the best 32-row plan is ONE launch that loads the
+  // CUs evenly (workgroups >= 90 % of a multiple of 256; B = 4: 512 tiles of 64x128, +1.7 % in the forward when the family took it)
+  // the family has to beat it by 3 %: between near-ties the plans that forward A/B runs settled at the BASELINE
   // configurations stay (with the family allowed everywhere configs 2 / 4 / 5 measured 5.21-5.32 / 55.93-55.95 / 12.18-12.19 ms
   // against 5.23 / 55.91-55.93 / 12.16-12.17 without it).  Against a cut plan or badly filled steps: 1 %.
   if (tile16_enabled()) {
     float margin = 1.01f;
     if (best.main_rows == 0 && best.rem.fam == F32) {
-      const long w = tile_wgs(best.rem.id, M, N);
-      const long slots = 256 * (best.rem.id == T64W ? 2 : best.rem.id == T64 ? 3 : best.rem.id >= T64N ? 4 : 1);  // co-resident workgroups per CU
-      if ((double)w / (double)(((w + slots - 1) / slots) * slots) >= 0.9) margin = 1.03f;
+      const long w = tile_wgs(best.rem.id, M, N);  // balance over the 256 CUs (co-resident workgroups share a CU's matrix pipe)
+      if ((double)w / (double)(((w + 255) / 256) * 256) >= 0.9) margin = 1.03f;
     }
     if (N % 256 == 0)
       for (int sl = F16W_MIN; sl <= F16W_MAX; ++sl) {

@@ -74,6 +74,7 @@ hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st, const LaunchTimin
 // {bm, bn, rows} of the main launch, {bm, bn, rows} of the remainder (0 = none), the MFMA tile edge of the launch(es) (32 / 16),
 // the cost model's estimate in us
 bool conv_gemm_plan(int M, int N, int Cin, int KW, int out[8]);
+bool conv_gemm_tile16_enabled();  // the 16-row tile family is in use (planner on, NS_TILE16 != 0)
 int conv_gemm_row_tile(int M, int N);  // height of the full-row (LayerNorm epilogue) tile for M rows of N = 256 / 512 columns
 // NS_PLAN=0 in the environment: the round-3 one-tile-per-launch rules (A/B runs of the planner; read once)
 bool launch_planner_enabled();
