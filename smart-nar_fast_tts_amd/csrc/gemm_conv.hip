@@ -761,6 +761,8 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
       if (wgs(rows32, 64) > 256) {
         // between one and two rounds of that tile (B = 9 ... 12 utterances: 285 workgroups took as long as 512): 48 rows tall, one round
         if (tile16_enabled() && rows32 > 256 && (p.M + 47) / 48 <= 256) return launch_t<48, 96, 32, 4, 1, 3, false, 0, 16>(p, st, tm);
+        // between two and three rounds (B = 17 ... 20): 80 rows tall, one round, 15 waves as 5 x 3 with one K loop each
+        if (tile16_enabled() && rows32 > 512 && (p.M + 79) / 80 <= 256) return launch_t<80, 96, 32, 1, 5, 3, false, 0, 16>(p, st, tm);
         return launch_t<32, 96, 32, 4, 1, 3>(p, st, tm);
       }
     } else {
