@@ -100,15 +100,17 @@ def test_500_forwards_on_four_streams_are_bit_identical_to_the_first():
 
 
 def test_fuzz_slice_vs_oracle():
-    """~50 random cases in at most ~70 s: tiny / tiny512 / tiny_h4 models (d_k 128 / 64 / 32), both feature levels, both
+    """38 random cases (~50 s): tiny / tiny512 / tiny_h4 models (d_k 128 / 64 / 32), both feature levels, both
     length regulators, control factors, ragged batches (most of them on packed rows), plus a few large batches that take the
     full-row tiles and the step-aware plan."""
     from tests import fuzz_gpu
 
-    small = fuzz_gpu.run(types.SimpleNamespace(iters=44, seed=4, matmul="fp32", big=False), max_seconds=55)
-    big = fuzz_gpu.run(types.SimpleNamespace(iters=8, seed=5, matmul="fp32", big=True), max_seconds=45)
-    assert small["checked"] >= 25 and small["packed"] >= 8, small
-    assert big["checked"] >= 4, big
+    # (a fixed number of cases; the time limits are a safety net sized for a box whose host cores run the oracle at half the usual
+    #  speed — round 5 met one: 23 of 44 cases in the old 55 s box — not what decides how many cases are compared)
+    small = fuzz_gpu.run(types.SimpleNamespace(iters=32, seed=4, matmul="fp32", big=False), max_seconds=240)
+    big = fuzz_gpu.run(types.SimpleNamespace(iters=6, seed=5, matmul="fp32", big=True), max_seconds=180)
+    assert small["checked"] + small["skipped"] == 32 and small["checked"] >= 25 and small["packed"] >= 8, small
+    assert big["checked"] + big["skipped"] == 6 and big["checked"] >= 4, big
     for r in (small, big):
         assert r["worst"]["mel"] < 1e-3 and r["worst"]["postnet"] < 1e-3, r
 
