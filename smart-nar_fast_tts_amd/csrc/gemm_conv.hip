@@ -680,10 +680,10 @@ bool conv_gemm_plan(int M, int N, int Cin, int KW, int out[8]) {
 // 117 -> 98 (80 rows); fc + LN 26.8 -> 22.4, 40.3 -> 35.1; predictor conv + LN 59 -> 47.5, 92 -> 76.5; M = 16 160 unchanged (64 = 2 x 32).
 int conv_gemm_row_tile(int M, int N) {
   if (!launch_planner_enabled() || !tile16_enabled()) return 32;
-  const int max_bm = N == 256 ? 128 : 112;  // (512 columns: the two B staging buffers alone are 128 KB of the CU's 160)
+  (void)N;  // (256 and 512 columns take the same heights; at 512 the two B staging buffers alone are 128 KB of the CU's 160: 112 rows fit)
   long best = 32 * ((((long)M + 31) / 32 + 255) / 256);
   int bm = 32;
-  for (int c = 48; c <= max_bm; c += 16) {
+  for (int c = 48; c <= 112; c += 32) {  // 48, 80, 112: the odd multiples of 16 — an even one only ever ties rounds of the 32-row tile
     const long rows = (long)c * ((((long)M + c - 1) / c + 255) / 256);
     if (rows < best) { best = rows; bm = c; }
   }
@@ -722,23 +722,19 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
     // full-row tile: 32 rows x N columns, N / 32 waves side by side with one 32x32 MFMA tile each
     if (!conv_gemm_row_epilogue_ok(p.M, p.N, p.Cin) || (p.epi == EPI_LN && p.ldy != p.N) || (p.resid && (p.ldr & 3))) return hipErrorInvalidValue;
     // (the height follows the row count: conv_gemm_row_tile above; 16 waves side by side in the 16-row family)
+    // (the heights the rule can pick: a 64- / 96- / 128-row tile only ever TIES two / three / four rounds of the 32-row one)
     const int bm = conv_gemm_row_tile(p.M, p.N);
     if (p.N == 256) {
       switch (bm) {
         case 48: return launch_t<48, 256, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
-        case 64: return launch_t<64, 256, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
         case 80: return launch_t<80, 256, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
-        case 96: return launch_t<96, 256, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
         case 112: return launch_t<112, 256, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
-        case 128: return launch_t<128, 256, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
         default: return launch_t<32, 256, 32, 1, 1, 8, true>(p, st, tm);
       }
     }
     switch (bm) {
       case 48: return launch_t<48, 512, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
-      case 64: return launch_t<64, 512, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
       case 80: return launch_t<80, 512, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
-      case 96: return launch_t<96, 512, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
       case 112: return launch_t<112, 512, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
       default: return launch_t<32, 512, 32, 1, 1, 16, true>(p, st, tm);
     }

@@ -528,6 +528,29 @@ def test_planner_shapes_vs_oracle(B):
     print(f"B={B}:", r)
 
 
+@pytest.mark.parametrize("cfg_name,B,height", [("tiny", 9, 48), ("tiny", 17, 80), ("tiny", 25, 112), ("tiny512", 9, 48), ("tiny512", 17, 80),
+                                                ("tiny512", 25, 112)])
+def test_full_row_tile_heights_vs_oracle(cfg_name, B, height):
+    """Every height of the full-row (GEMM + LayerNorm / predictor-tail epilogue) tile the plan can pick — 48, 80 and 112 rows of the
+    16-row family, one- and two-pass row epilogues — at both row widths (256 and 512 columns: the 1+1-layer fixtures models), each
+    against the oracle on every frame with the bucket decisions pinned.  B x ~1010 rows put the fullest CU at 35.5 / 67 / 98.6 rows;
+    ns_plan_row_tile must answer the height the case is named for (transformer/SubLayers.py:56-57,92-93; model/modules.py:245-286)."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from oracle import fs2_oracle as orc
+
+    meta = dict(config=cfg_name, weight_seed=0, frames_per_phoneme=8.0, dur_weight_scale=0.25)
+    cfg, sd, m = gpu_model(meta)
+    w = orc.to_torch_weights(sd)
+    inp, ref = _screened_full_batch(w, cfg, B, 128, seed=40 + B)
+    T = int(ref[9].max())
+    d = cfg["transformer"]["decoder_hidden"]
+    assert int(m._lib.ns_plan_row_tile(B * T, d)) == height, (B * T, d, int(m._lib.ns_plan_row_tile(B * T, d)))
+    r = _pinned_vs_oracle(m, w, cfg, inp, ref, f"{cfg_name} B={B} full-row tile {height}")
+    r.pop("out")
+    print(f"{cfg_name} B={B} rows {B * T} full-row tile {height} x {d}:", r)
+    _MODEL.clear()
+
+
 class _ShardedGlobalPad:
     """Runs a batch as contiguous shards, one forward each on the one GPU, every shard padded to the GLOBAL longest mel
     (forward(max_mel_len=callable), the value sharding.global_max would all-reduce) and returns the concatenated 12-tuple:
