@@ -224,7 +224,7 @@ int ns_op_attention_core(const float* qkv, const int64_t* lens, int B, int S, in
  * narrow-channel rules (then out is zeroed).  All rows of one GEMM are summed in one order: a cut is only ever made between tiles
  * of the 32-row family, which share it, so it never shows in the bits.
  * ns_plan_row_tile: height of the full-row tile (GEMM + LayerNorm / predictor-tail epilogue, N = 256 or 512 = one activation
- * row) for M rows: 32, or a multiple of 16 up to 128 when that gives the fullest CU fewer rows; 0 for other widths.
+ * row) for M rows: 32, or 48 / 80 / 112 (16-row family) when that gives the fullest CU fewer rows; 0 for other widths.
  * ns_plan_attention_split: key ranges per 128-query tile of a dense attention launch (1 = none; 16 = the small-grid paths' own
  * sizing, the value the workspace is reserved for). */
 int ns_plan_gemm(int M, int N, int Cin, int KW, int32_t out[8]);
