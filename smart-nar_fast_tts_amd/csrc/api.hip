@@ -539,7 +539,8 @@ static int gemm(const Scratch& sc, const float* X, int ldx, const float* W, cons
 }
 
 // A GEMM whose N columns are one whole activation row can run the row's LayerNorm in its epilogue (kernels.h
-// RowEpilogue).  The full-row tile is 32 rows tall, so it is taken once the launch has about a workgroup per CU;
+// RowEpilogue).  The full-row tile is at least 32 rows tall (48 / 80 / 112 between the steps: gemm_conv.hip conv_gemm_row_tile), so it
+// is taken once the launch has about a workgroup per CU;
 // below that the many-small-tiles + split-K ladder followed by the row kernel is faster (tools/lab/gemm_lab_ln.hip:
 // M=16160 K=1024 93 -> 85 us, K=256 39.5 -> 31 us; M=2048 K=1024 21.6 -> 43 us).
 static bool fuse_row_epilogue(int M, int N, int Cin) {

@@ -11,7 +11,7 @@
 // window.  K is indexed tap-major in memory (k = j*Cin + c), BK divides Cin, so one K-chunk touches one tap.
 //
 // Tiling (wave64): block tile BMxBN computed by WGM x WGN waves, wave tile (BM/WGM)x(BN/WGN) as a grid of 32x32 MFMA
-// tiles, K-chunk BK double-buffered in LDS.  KS > 1 adds an in-workgroup split of K: KS groups of waves each take
+// tiles (MF = 32) or 16x16 ones (MF = 16: block tiles of any multiple of 16 rows, see k_conv_gemm), K-chunk BK double-buffered in LDS.  KS > 1 adds an in-workgroup split of K: KS groups of waves each take
 // every KS-th chunk into their own accumulators and the partial tiles are summed through LDS at the end.  It is
 // used when the output has too few tiles to occupy the chip (the encoder's [B*L, *] GEMMs, single-utterance
 // latency): the serial K loop of a tile, not the matrix pipe, bounds those launches.
@@ -29,7 +29,8 @@
 // (SQ_LDS_BANK_CONFLICT = 0 in profiles/r01_pmc.md).
 //
 // Operand reads use the freedom to permute k identically on both operands: lane-half h of MFMA step e in
-// group g consumes k = 8g + 4h + e, so each lane reads its 4 steps' operands with ONE ds_read_b128.
+// group g consumes k = 8g + 4h + e (MF = 16: lane-quarter q, k = 16g + 4q + e), so each lane reads its 4 steps' operands with
+// ONE ds_read_b128.
 #include <hip/hip_ext.h>
 #include <cstdlib>
 #include <type_traits>
@@ -719,7 +720,7 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
 #undef NS_TICKET_LADDER
   }
   if (p.epi != EPI_NONE) {
-    // full-row tile: 32 rows x N columns, N / 32 waves side by side with one 32x32 MFMA tile each
+    // full-row tile: BM rows x N columns, the waves side by side (32 rows: N / 32 waves with one 32x32 MFMA tile each)
     if (!conv_gemm_row_epilogue_ok(p.M, p.N, p.Cin) || (p.epi == EPI_LN && p.ldy != p.N) || (p.resid && (p.ldr & 3))) return hipErrorInvalidValue;
     // (the height follows the row count: conv_gemm_row_tile above; 16 waves side by side in the 16-row family)
     // (the heights the rule can pick: a 64- / 96- / 128-row tile only ever TIES two / three / four rounds of the 32-row one)
