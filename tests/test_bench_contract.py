@@ -133,6 +133,22 @@ def test_bench_plain_command_launches_its_own_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_ragged_shards_are_balanced_by_phonemes():
+    """`python bench.py --gpus 2 --ragged` (one-GPU rig): a ragged global batch is split longest-first on the phoneme counts
+    (sharding.shard_indices(balance="phonemes"); SURVEY.md section 8e names per-shard imbalance as the scaling risk) and the line
+    says so: the balance mode, the phonemes every rank received, and the measured spread of rows and valid frames."""
+    d = _run(["--gpus", "2", "--ragged", "--steps", "2", "--warmup", "1", "--no-extras"], env={"NS_BENCH_ONE_GPU": "1"})
+    rs = d["rank_spread"]
+    assert rs["balance"] == "phonemes" and d["config"]["shard_balance"] == "phonemes" and len(rs["phonemes_per_rank"]) == 2
+    assert abs(rs["phonemes_per_rank"][0] - rs["phonemes_per_rank"][1]) <= 8, rs
+    assert 1.0 <= rs["valid_frames_max_over_min"] <= 1.05 and rs["rows_phase2_max_over_min"] >= 1.0, rs
+    c = _run(["--gpus", "2", "--ragged", "--balance", "count", "--steps", "2", "--warmup", "1", "--no-extras"], env={"NS_BENCH_ONE_GPU": "1"})
+    assert c["rank_spread"]["balance"] == "count"
+    spread = lambda x: max(x["rank_spread"]["phonemes_per_rank"]) - min(x["rank_spread"]["phonemes_per_rank"])  # noqa: E731
+    assert spread(d) <= spread(c)
+
+
+@pytest.mark.gpu
 def test_bench_one_rank_over_rccl():
     """The N > 1 code path over the real backend ("nccl" = RCCL) with the one rank a test box can give it: process-group
     init bound to the device, the weight-arena broadcast, the all-reduces of the timing block and the all-gather of the
