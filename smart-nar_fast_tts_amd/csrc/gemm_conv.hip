@@ -713,6 +713,9 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
 #define NS_TICKET_LADDER(NVT)                                                                                                        \
     if (wgs(rows32, 32) <= 256) return nch >= 16 ? launch_t<32, 32, 32, 8, 1, 1, false, NVT>(p, st, tm) : launch_t<32, 32, 32, 4, 1, 1, false, NVT>(p, st, tm); \
     if (wgs(rows32, 64) <= 256) return launch_t<32, 64, 32, 4, 1, 2, false, NVT>(p, st, tm);                                             \
+    /* between one and two rounds of that rung (B = 17 ... 24 encoder grids): 48 rows tall, one round (16-row family) */                 \
+    if (launch_planner_enabled() && tile16_enabled() && wgs((p.M + 47) / 48, 64) <= 256)                                                 \
+      return launch_t<48, 64, 32, 4, 1, 2, false, NVT, 16>(p, st, tm);                                                                   \
     if (wgs(rows32, 128) <= 512) return launch_t<32, 128, 32, 2, 1, 4, false, NVT>(p, st, tm);                                           \
     return hipErrorInvalidValue; /* (unreachable: conv_gemm_ticket_ok bounds the tile count) */
     if (p.N == 256) { NS_TICKET_LADDER(1) }
@@ -841,13 +844,18 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
     const int nch = p.KW * (p.Cin / 32);
     if (wgs(rows32, 32) <= 256) return nch >= 16 ? launch_t<32, 32, 32, 8, 1, 1>(p, st, tm) : launch_t<32, 32, 32, 4, 1, 1>(p, st, tm);
     if (wgs(rows32, 64) <= 256) return launch_t<32, 64, 32, 4, 1, 2>(p, st, tm);
+    // (row widths the ticketed ladder above serves: the same rungs in the same places, so that the two-launch form of a row epilogue —
+    //  this GEMM, then the row kernel — sums every row like the ticketed launch it stands in for: ns_config.row_epilogue, same bits)
+    const bool row_width = p.N == 256 || p.N == 512;
+    if (row_width && launch_planner_enabled() && tile16_enabled() && wgs((p.M + 47) / 48, 64) <= 256)
+      return launch_t<48, 64, 32, 4, 1, 2, false, 0, 16>(p, st, tm);
     // (a square 64 x 64 KS4 tile on 16 waves for long-K launches of about one workgroup per CU — (64 + 64) operand rows per CU instead of
     //  (32 + 128) — measured 47.5 -> 44.9 us in the lab at M = 788 and nothing in the forward: single utterance 0.8443 / 0.8419 ms without,
     //  0.8421 / 0.8408 with, alternating runs; not taken.  tools/lab/gemm_lab_r5b.hip)
     if (wgs(rows32, 128) <= 512) {
       // between one and two rounds of the 32x128 rung (B = 9 ... 12 encoder grids: 288 workgroups took as long as 512): the same
       // rung 48 rows tall, one round (16-row family; tools/lab/gemm_lab_mf16.hip, k9 256->1024: M = 1152 80.5 -> 63.1 us, 1408 79.6 -> 63.9)
-      if (launch_planner_enabled() && tile16_enabled() && wgs(rows32, 128) > 256 && wgs((p.M + 47) / 48, 128) <= 256)
+      if (!row_width && launch_planner_enabled() && tile16_enabled() && wgs(rows32, 128) > 256 && wgs((p.M + 47) / 48, 128) <= 256)
         return launch_t<48, 128, 32, 2, 1, 4, false, 0, 16>(p, st, tm);
       return launch_t<32, 128, 32, 2, 1, 4>(p, st, tm);
     }

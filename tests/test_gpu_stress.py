@@ -59,6 +59,10 @@ def test_ticketed_epilogues_match_the_two_launch_form_bit_for_bit():
     cases.append(("cfg1_single", cfg1, sd1, wl.synth_inputs(1, 100, seed=0)))
     cases.append(("ragged batch of 5", cfg1, sd1, wl.synth_inputs(5, 64, seed=3, src_lens=[64, 9, 33, 50, 17])))
     cases.append(("ragged batch of 3, short", cfg1, sd1, wl.synth_inputs(3, 20, seed=4, src_lens=[20, 13, 7])))
+    # the ladder's 48-row rungs (16-row family): 18 x 128 = 2304 encoder rows take the ticketed 48 x 64 K-split tile, 5 x ~1010 decoder
+    # rows the ticketed 32 x 128 one while other launches of the same forwards run on the family's tiles
+    cases.append(("uniform batch of 18", cfg1, sd1, wl.synth_inputs(18, 128, seed=6)))
+    cases.append(("uniform batch of 5", cfg1, sd1, wl.synth_inputs(5, 128, seed=7)))
     built = {}
     for name, cfg, sd, inp in cases:
         key = id(sd)
