@@ -80,6 +80,24 @@ def is_plain_gemm(n):
     return "k_conv_gemm<" in n and re.search(r"false, 0(, \d+)?>", n) is not None
 
 
+def tile_rows(n):
+    m = re.search(r"k_conv_gemm<(\d+),", n)
+    return int(m.group(1)) if m else 0
+
+
+def compatible(op, k):
+    """An operation that carries a row epilogue ("+LN") runs on a full-row or ticketed GEMM kernel — or, in the two-launch form, on a
+    plain one followed by the row kernel; a plain operation never runs on a row-epilogue kernel.  Without this the backtracking can
+    line the sequence up one position late (round 5, config 4: a cut FFN w_1 read as one launch and the slack absorbed further down)."""
+    n = names[k]
+    if "k_conv_gemm<" not in n:
+        return True
+    row_op = "+LN" in op
+    if is_plain_gemm(n):
+        return (not row_op) or (k + 1 < len(names) and ("k_layernorm" in names[k + 1] or "k_ln_linear_embed" in names[k + 1]))
+    return row_op
+
+
 sys.setrecursionlimit(10000)
 memo = {}
 
@@ -102,15 +120,17 @@ def match(i, k):
             if res is None:
                 rest = match(i + 1, k)
                 res = rest
-        elif k < len(names):
-            rest = match(i + 1, k + 1)
-            if rest is not None:
-                res = [(op, fl, 1)] + rest
-            elif (any(t in op for t in SPLITTABLE) and k + 1 < len(names) and is_plain_gemm(names[k]) and is_plain_gemm(names[k + 1])
-                  and re.sub(r"\(.*", "", names[k]) != re.sub(r"\(.*", "", names[k + 1])):
+        elif k < len(names) and compatible(op, k):
+            # a cut plan first (a tall plain tile followed by a finer plain tile of the same operation), then the single launch
+            if (any(t in op for t in SPLITTABLE) and k + 1 < len(names) and is_plain_gemm(names[k]) and is_plain_gemm(names[k + 1])
+                    and tile_rows(names[k]) > tile_rows(names[k + 1])):  # main tile first, then the finer remainder
                 rest = match(i + 1, k + 2)
                 if rest is not None:
                     res = [(op, fl, 2)] + rest
+            if res is None:
+                rest = match(i + 1, k + 1)
+                if rest is not None:
+                    res = [(op, fl, 1)] + rest
     memo[key] = res
     return res
 
