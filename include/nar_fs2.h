@@ -63,8 +63,8 @@ typedef struct ns_config {
                                ever drawn.  Same bits either way — the switch exists so that tests can A/B the ticket protocol
                                (tests/test_gpu_stress.py).  The full-row tile of large launches needs no ticket and is not affected */
   int32_t phase1_packing;   /* ns_forward_durations_packed: 0 = auto — pack the phoneme rows when >= 10 % of the [B, L] grid is padding AND the
-                               smaller row count saves a whole step of 256 workgroups of the phase's dominant launch (small grids: time
-                               is steps, not rows); 1 = pack whenever >= 10 % is padding (tests exercise the path on small shapes);
+                               smaller row count gives the fullest CU fewer rows of the phase's dominant launch (a whole round of its 32-row
+                               K-split tile less, or one round of the 48-row form instead of two of the 32-row one); 1 = pack whenever >= 10 % is padding (tests exercise the path on small shapes);
                                2 = never */
 } ns_config;
 
