@@ -364,11 +364,17 @@ def main():
     sp, tx, ln, _ = wl.synth_inputs(B_shard * world, L, seed=0, src_lens=ragged)
     balance = args.balance or ("phonemes" if args.ragged else "count")
     shard_phonemes = [int(np.asarray(ln)[p].sum()) for p in sharding.shard_indices(ln, world, balance)]
-    sp, tx, ln, Lmax = sharding.shard_batch(sp, tx, ln, world, rank, balance=balance)
-    speakers, texts, src_lens = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (sp, tx, ln))
-    if args.host_lens:
-        src_lens = torch.from_numpy(np.ascontiguousarray(ln))
-    pad_fn = sharding.global_max if (args.global_pad and world > 1) else None
+    # this rank's share through the sharded entry point's own pieces (sharding.prepare_shard / forward_shard: what
+    # sharding.synthesize_sharded composes) — inputs resident on the device before the timed region, and in global-pad mode the
+    # deadlock-free exchange (a rank with no utterances, or one whose forward raises, still joins the all-reduce)
+    n_all = B_shard * world
+    host_batch = ([f"utt{i}" for i in range(n_all)], [""] * n_all, sp, tx, ln, int(tx.shape[1]))
+    shard = sharding.prepare_shard(host_batch, dev, balance=balance, host_lens=bool(args.host_lens), world_size=world, rank=rank)
+    speakers, texts, src_lens, Lmax = shard.batch[2], shard.batch[3], shard.batch[4], shard.batch[5]
+    sp, tx, ln = sp[shard.index], tx[shard.index], ln[shard.index]
+    global_pad = bool(args.global_pad and world > 1)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    spin_us = sharding.configure_spin(model, local_world_size=local_world)
 
     # --streams S > 1: consecutive steps go round-robin onto S HIP streams, so the small-grid phase 1 of step i+1 (and
     # the host read of mel_lens between the phases) overlaps the chip-filling phase 2 of step i.  Same K steps, same work.
@@ -377,11 +383,11 @@ def main():
 
     def step():
         if streams is None:
-            return model(speakers, texts, src_lens, Lmax, max_mel_len=pad_fn)
+            return sharding.forward_shard(model, shard, global_pad)
         st = streams[counter[0] % len(streams)]
         counter[0] += 1
         with torch.cuda.stream(st):
-            return model(speakers, texts, src_lens, Lmax, max_mel_len=pad_fn)
+            return sharding.forward_shard(model, shard, global_pad)
 
     def fence():
         torch.cuda.synchronize()
@@ -432,12 +438,12 @@ def main():
             ps = [torch.cuda.Stream(device=dev) for _ in range(2)]
             for i in range(2):
                 with torch.cuda.stream(ps[i]):
-                    model(speakers, texts, src_lens, Lmax, max_mel_len=pad_fn)
+                    model(speakers, texts, src_lens, Lmax)
             torch.cuda.synchronize()
             t0p = time.perf_counter()
             for i in range(args.steps):
                 with torch.cuda.stream(ps[i % 2]):
-                    model(speakers, texts, src_lens, Lmax, max_mel_len=pad_fn)
+                    model(speakers, texts, src_lens, Lmax)
             torch.cuda.synchronize()
             pipelined = time.perf_counter() - t0p
             # ... and in capacity mode (max_mel_len = this batch's padded length, as a server with a bucket ceiling passes it;
@@ -465,7 +471,9 @@ def main():
                  "rows_phase2": int(model._lib.ns_last_phase2_rows(model._h)),  # B*T_pad on the grid, fewer on packed rows (ragged batches)
                  "hsa_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "omp_num_threads": os.environ.get("OMP_NUM_THREADS"),
                  "launcher": os.environ.get("NS_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "none"),
-                 "cpu_affinity": affinity, "init_s": round(t_ready - t_init0, 3)}]
+                 "cpu_affinity": affinity, "init_s": round(t_ready - t_init0, 3),
+                 # busy-wait budget of the mid-forward hand-over, set from the ranks sharing this host (sharding.spin_budget_us)
+                 "spin_us": spin_us, "local_world_size": local_world, "utterances": len(shard)}]
     world_seen = 1
     if dist is not None:
         tmax = stats.clone()
@@ -594,7 +602,7 @@ def main():
                                f"{cfg['transformer']['encoder_layer']}+{cfg['transformer']['decoder_layer']} FFT layers, "
                                f"random-init weights (seed 0, duration bias log({fpp + 1:g}))",
                    "global_batch": B_shard * args.gpus, "valid_frames_per_step": int(frames_total),
-                   "padding": "global-pad" if pad_fn else "per-shard", "shard_balance": balance,
+                   "padding": "global-pad" if global_pad else "per-shard", "shard_balance": balance,
                    "algorithmic_mflop_per_frame": round(flops_frame / 1e6, 2),
                    "end_to_end_tflops": round(flops_frame * value / 1e12, 2)},
         "roofline": {"bound": "mfma", "kernel": "k_conv_gemm (FFN w_1: Conv1d k=9, d->d_inner, bias+ReLU)",

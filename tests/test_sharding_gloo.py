@@ -189,3 +189,238 @@ def test_two_rank_weight_broadcast_and_shards_on_gpu():
         assert np.array_equal(post, ref[1].cpu().numpy()), f"rank {rank}: adopted weights give different bits"
         tmax = max(tmax, int(mel_lens.max()))
     assert all(r[3] == tmax for r in res), "global-pad mode: every shard pads to the global longest mel"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sharding.synthesize_sharded: the N-rank form of synthesize.py:59-76 — no rank may leave another waiting in a collective
+# ---------------------------------------------------------------------------------------------------------------------
+
+class _HostModel:
+    """A host stand-in with forward()'s call surface (model/fastspeech2_align.py:30-43 + the ``max_mel_len`` callable of the real
+    wrapper): per-utterance outputs are a pure function of the utterance's own tokens, so sharded == whole batch per utterance.
+    TEST DOUBLE for the host logic only (the CPU suite has no GPU); the one-GPU rig below runs the real model."""
+
+    N_VOCAB, N_MEL = 361, 80
+
+    def __call__(self, speakers, texts, src_lens, max_src_len, max_mel_len=None, p_control=1.0, e_control=1.0):
+        import numpy as np
+
+        B, L = texts.shape
+        assert int(max_src_len) == L
+        lens = torch.as_tensor(np.asarray(src_lens)).long()
+        if int(texts.max()) >= self.N_VOCAB:
+            raise IndexError("index out of range in self")  # raised BEFORE the pad exchange, like the real forward
+        valid = torch.arange(L)[None, :] < lens[:, None]
+        d = ((texts % 3) + 1) * valid
+        mel_lens = d.sum(1)
+        T = int(mel_lens.max())
+        if callable(max_mel_len):
+            T = int(max_mel_len(torch.tensor(T)))
+        t = torch.arange(T)[None, :]
+        pad = t >= mel_lens[:, None]
+        seed = (texts * valid).sum(1).float()[:, None]
+        pitch = ((seed + t) * p_control).masked_fill(pad, 0.0)
+        energy = ((seed - t) * e_control).masked_fill(pad, 0.0)
+        mel = (seed[:, :, None] + 1e-3 * t[:, :, None] + 1e-5 * torch.arange(self.N_MEL)[None, None, :]).masked_fill(pad[:, :, None], 0.0)
+        return (mel - 1.0, mel, pitch, energy, torch.log1p(d.float()), d.float(), ~valid, pad, src_lens, mel_lens, None, None)
+
+
+def _host_batch(n, L=9, bad=None):
+    import numpy as np
+
+    from smart_nar_fast_tts_amd import batching
+
+    rs = np.random.RandomState(5)
+    lens = rs.randint(1, L + 1, size=n)
+    lens[0] = L
+    data = [(f"utt{i}", 0, rs.randint(1, 361, size=int(k)).astype(np.int64), f"text {i}") for i, k in enumerate(lens)]
+    if bad is not None:
+        data[bad][2][0] = 400  # outside the vocabulary
+    return batching.collate(data)
+
+
+def _synth_worker(rank, world, port, q, n, global_pad, balance, bad):
+    import numpy as np
+
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model, pc = _HostModel(), wl.preprocess_config()
+        batch = _host_batch(n, bad=bad)
+        try:
+            res, idx = sharding.synthesize_sharded(model, batch, pc, device="cpu", balance=balance, global_pad=global_pad, gather=True)
+            shard = sharding.prepare_shard(batch, "cpu", balance)
+            out = sharding.forward_shard(model, shard, global_pad)
+            t_pad = None if out is None else int(out[1].shape[1])
+            q.put((rank, "ok", [(r["index"], r["basename"], r["mel_len"], r["src_len"], r["mel"].numpy(), r["pitch"], r["energy"], r["duration"]) for r in res],
+                   np.asarray(idx).tolist(), t_pad, len(shard)))
+        except Exception as e:  # noqa: BLE001
+            q.put((rank, type(e).__name__, str(e), None, None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_synth(n, global_pad, balance="count", bad=None, world=2):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_synth_worker, args=(r, world, port, q, n, global_pad, balance, bad)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted((q.get(timeout=90) for _ in range(world)), key=lambda r: r[0])  # a hang IS the failure this test exists for
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    return res
+
+
+@pytest.mark.parametrize("n", [1, 5])
+@pytest.mark.parametrize("global_pad", [False, True])
+def test_synthesize_sharded_two_ranks(n, global_pad):
+    """n = 5: ranks take 3 + 2 utterances; n = 1: rank 1 gets NOTHING and must still join every collective (global-pad's all-reduce,
+    the gather's all-gather).  Rank 0's gathered result is the whole batch in its original order and equals the unsharded call."""
+    import numpy as np
+
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd import batching
+
+    res = _run_synth(n, global_pad)
+    assert [r[1] for r in res] == ["ok", "ok"], res
+    batch = _host_batch(n)
+    whole = batching.synthesize(_HostModel(), [batch], wl.preprocess_config(), device="cpu")
+    rank0, rank1 = res
+    assert rank0[3] == list(range(n)) and [x[0] for x in rank0[2]] == list(range(n))
+    for got, ref in zip(rank0[2], whole):
+        assert got[1] == ref["basename"] and got[2] == ref["mel_len"] and got[3] == ref["src_len"]
+        assert np.array_equal(got[4], ref["mel"].numpy()) and np.array_equal(got[5], ref["pitch"]) and np.array_equal(got[6], ref["energy"])
+        assert np.array_equal(got[7], ref["duration"])
+    # the other rank keeps its own share (empty for n = 1)
+    assert rank1[3] == list(range((n + 1) // 2, n)) and rank1[5] == n // 2
+    if global_pad:
+        t_global = max(r["mel_len"] for r in whole)
+        assert [r[4] for r in res] == ([t_global, t_global] if n > 1 else [t_global, None])
+
+
+def test_synthesize_sharded_lpt_balance():
+    import numpy as np
+
+    res = _run_synth(5, True, balance="phonemes")
+    assert [r[1] for r in res] == ["ok", "ok"], res
+    assert res[0][3] == list(range(5)) and sorted(res[0][3][:0] + [x[0] for x in res[0][2]]) == list(range(5))
+    assert res[0][5] + res[1][5] == 5 and np.all(np.diff(res[1][3]) > 0)
+
+
+@pytest.mark.parametrize("n,bad", [(5, 4), (5, 0), (1, 0)])
+def test_synthesize_sharded_failure_does_not_hang(n, bad):
+    """A forward that raises before its exchange (a token id outside the vocabulary -> IndexError, transformer/Models.py:89) must
+    not leave the other rank in the all-reduce: the failing rank joins it with the flag set and re-raises its own error, every
+    other rank — also one with an empty shard — raises PeerFailure."""
+    res = _run_synth(n, True, bad=bad)
+    owner = 0 if bad < (n + 1) // 2 else 1
+    assert res[owner][1] == "IndexError", res
+    assert res[1 - owner][1] == "PeerFailure", res
+
+
+def test_spin_budget_follows_the_local_rank_count(monkeypatch):
+    from smart_nar_fast_tts_amd import sharding
+
+    monkeypatch.delenv("NS_SPIN_US", raising=False)
+    assert sharding.spin_budget_us(1, cores=2) == 300.0
+    assert sharding.spin_budget_us(8, cores=128) == 300.0
+    assert sharding.spin_budget_us(8, cores=8) == 0.0  # eight ranks on eight cores must not spin
+    monkeypatch.setenv("NS_SPIN_US", "50")
+    assert sharding.spin_budget_us(8, cores=8) == 50.0
+
+    class M:
+        SPIN_US = 300.0
+
+    monkeypatch.delenv("NS_SPIN_US")
+    m = M()
+    assert sharding.configure_spin(m, local_world_size=8, cores=8) == 0.0 and m.SPIN_US == 0.0
+
+
+def test_synthesize_sharded_failure_in_per_shard_mode_does_not_hang_the_gather():
+    """Per-shard mode has no exchange on the data path, so a failing rank is only noticed at the gather: it joins the gather's
+    all-gather with the failure header set (then re-raises), and the healthy rank raises PeerFailure instead of waiting for rows."""
+    res = _run_synth(5, False, bad=4)
+    assert res[1][1] == "IndexError" and res[0][1] == "PeerFailure", res
+
+
+def _gpu_synth_worker(rank, world, port, q, n, global_pad):
+    """synthesize_sharded with the REAL model, both ranks on cuda:0, gloo for the collectives (host-staged)."""
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd import sharding
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = wl.model_config("tiny")
+        model = FastSpeech2Align(wl.preprocess_config(), cfg).to("cuda:0").eval()
+        model.load_state_dict(wl.synth_state_dict(cfg, seed=0, frames_per_phoneme=4.0))
+        spin = sharding.configure_spin(model, local_world_size=world)
+        res, idx = sharding.synthesize_sharded(model, _host_batch(n, L=24), wl.preprocess_config(), device="cuda:0",
+                                               global_pad=global_pad, gather=True)
+        torch.cuda.synchronize()
+        q.put((rank, [(r["index"], r["mel_len"], r["mel"].cpu().numpy(), r["pitch"], r["energy"], r["duration"]) for r in res], idx.tolist(), spin))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 5])
+@pytest.mark.parametrize("global_pad", [False, True])
+def test_synthesize_sharded_on_gpu_matches_single_process(n, global_pad):
+    """The one-GPU 2-rank rig: rank 0's gathered utterances, in the batch's order, against a single process running each rank's
+    shard by itself (per-shard mode) or padded to the global longest mel (global-pad mode) — bit for bit."""
+    import numpy as np
+
+    import smart_nar_fast_tts_amd.workload as wl
+    from smart_nar_fast_tts_amd import batching, sharding
+    from smart_nar_fast_tts_amd.model import FastSpeech2Align
+
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_synth_worker, args=(r, world, port, q, n, global_pad)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    cfg, pc = wl.model_config("tiny"), wl.preprocess_config()
+    model = FastSpeech2Align(pc, cfg).to("cuda").eval()
+    model.load_state_dict(wl.synth_state_dict(cfg, seed=0, frames_per_phoneme=4.0))
+    batch = _host_batch(n, L=24)
+    expect, t_global = {}, 0
+    shards = [sharding.prepare_shard(batch, "cuda", world_size=world, rank=r) for r in range(world)]
+    with torch.no_grad():
+        if global_pad:
+            t_global = max(int(model(*(s.batch[2:]))[9].max()) for s in shards if not s.empty)
+        for s in shards:
+            if s.empty:
+                continue
+            out = model(*(s.batch[2:]), max_mel_len=t_global if global_pad else None)
+            for item, gi in zip(batching.split_outputs(s.batch, out, pc), s.index):
+                expect[int(gi)] = item
+    got = res[0][1]
+    assert res[0][2] == list(range(n)) and [g[0] for g in got] == list(range(n)) and sorted(expect) == list(range(n))
+    for g in got:
+        e = expect[g[0]]
+        assert g[1] == e["mel_len"] and np.array_equal(g[5], e["duration"])
+        assert np.array_equal(g[2], e["mel"].cpu().numpy()), f"utterance {g[0]}: gathered mel differs from the single-process shard"
+        assert np.array_equal(g[3], e["pitch"]) and np.array_equal(g[4], e["energy"])
+    assert res[1][2] == list(range((n + 1) // 2, n))
+    assert all(r[3] == sharding.spin_budget_us(world) for r in res)

@@ -26,3 +26,55 @@ def weights_for(meta):
         _SD_CACHE.clear()  # one at a time: a full state dict is 116 MB
         _SD_CACHE[key] = (cfg, wl.synth_state_dict(cfg, seed=key[1], frames_per_phoneme=key[2], dur_weight_scale=key[3]))
     return _SD_CACHE[key]
+
+
+F64_FIXTURES = {"f64_cfg1": "pin_cfg1_single", "f64_cfg2": "pin_cfg2_b16", "f64_cfg4": "pin_cfg4_d512", "f64_cfg5": "pin_cfg5_longform"}
+
+
+def _dist_stats(d):
+    d = np.asarray(d, dtype=np.float64).reshape(-1)
+    if d.size == 0:
+        return {"max": 0.0, "p999": 0.0, "median": 0.0, "n": 0}
+    return {"max": float(d.max()), "p999": float(np.quantile(d, 0.999)), "median": float(np.median(d)), "n": int(d.size)}
+
+
+def accuracy_against_float64(name, model, sd):
+    """|HIP - float64| beside |reference-fp32 - float64| on one float64 fixture (tests/golden/f64_cfg*.npz, written by
+    tools/reference_self_deviation.py from the imported reference cast to .double(), bucket decisions pinned to the fp32
+    reference's own predictions).  The HIP forward takes the SAME decisions (p_targets / e_targets = the fp32 pin's predictions),
+    so all three evaluations compute the same function and differ in arithmetic only.
+
+    Returns ``{quantity: {"hip": stats, "ref32": stats}}`` with stats = max / p99.9 / median; pitch and energy relative to
+    max(|truth|, 1) on the frames inside the bin range (oracle/parity.py), log-duration and the two mels absolute, mels on every
+    ``frame_stride``-th frame (what the fixture holds)."""
+    import torch
+
+    from oracle import parity
+
+    meta64, z64 = load_golden(name)
+    meta, z = load_golden(meta64["source_pin"])
+    stride = int(meta64["frame_stride"])
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    with torch.no_grad():
+        out = model(dev(z["speakers"]), dev(z["texts"]), dev(z["in_src_lens"]), int(meta["L"]),
+                    p_targets=dev(z["p_predictions"]), e_targets=dev(z["e_predictions"]))
+    torch.cuda.synchronize()
+    assert np.array_equal(out[9].cpu().numpy(), z["mel_lens"]), (name, "frame counts differ from the reference's")
+    assert np.array_equal(out[5].cpu().numpy(), z["d_rounded"]), (name, "durations differ from the reference's")
+    valid = ~z["mel_masks"]
+    src_valid = np.arange(z["log_d_predictions"].shape[1])[None, :] < z["in_src_lens"][:, None]
+    vs = valid[:, ::stride]
+    res = {}
+
+    def both(key, hip, ref32, truth, sel, rel):
+        t = np.asarray(truth, dtype=np.float64)
+        den = np.maximum(np.abs(t), 1.0) if rel else 1.0
+        res[key] = {"hip": _dist_stats((np.abs(np.asarray(hip, dtype=np.float64) - t) / den)[sel]),
+                    "ref32": _dist_stats((np.abs(np.asarray(ref32, dtype=np.float64) - t) / den)[sel])}
+
+    both("log_d", out[4].cpu().numpy(), z["log_d_predictions"], z64["log_d_predictions"], src_valid, False)
+    for key, i, k, bins in (("pitch_rel", 2, "p_predictions", "variance_adaptor.pitch_bins"), ("energy_rel", 3, "e_predictions", "variance_adaptor.energy_bins")):
+        both(key, out[i].cpu().numpy(), z[k], z64[k], parity.in_range(z[k], np.asarray(sd[bins]), valid), True)
+    both("mel", out[0].cpu().numpy()[:, ::stride], z["output_sub"], z64["output_sub"], vs, False)
+    both("postnet", out[1].cpu().numpy()[:, ::stride], z["postnet_output_sub"], z64["postnet_output_sub"], vs, False)
+    return res
