@@ -32,6 +32,10 @@
 extern "C" {
 #endif
 
+/* Version of this header's contract, returned by ns_abi_version(): 6 = ns_plan_row_tile_k, ns_acc_chunk, ns_abi_version;
+ * 5 = ns_plan_gemm writes out[8] (round 5; unversioned then). */
+#define NS_ABI_VERSION 6
+
 typedef struct ns_model ns_model;
 
 /* Mirrors the keys FastSpeech2Align.__init__ reads from model.yaml / preprocess.yaml
@@ -228,7 +232,16 @@ int ns_op_attention_core(const float* qkv, const int64_t* lens, int B, int S, in
  * ns_plan_attention_split: key ranges per 128-query tile of a dense attention launch (1 = none; 16 = the small-grid paths' own
  * sizing, the value the workspace is reserved for). */
 int ns_plan_gemm(int M, int N, int Cin, int KW, int32_t out[8]);
-int ns_plan_row_tile(int M, int N);
+int ns_plan_row_tile(int M, int N);            /* = ns_plan_row_tile_k(M, N, N): the attention output projection's contraction */
+int ns_plan_row_tile_k(int M, int N, int K);   /* contraction length K = KW * Cin: K > 256 keeps to the heights with chunked accumulation */
+/* k values per accumulation chunk of the long contractions (K > 256; csrc/gemm_conv.hip ACC2): partial sums of this many
+ * products are formed from zero and then added to the running total, so that the matrix cores round against short sums.
+ * 64 by default; NS_ACC_CHUNK in the environment (a multiple of 64, or 0 = one sequential sum per output: A/B runs). */
+int ns_acc_chunk(void);
+/* Version of this header's contract (NS_ABI_VERSION below): bumped whenever a signature, an output-array length or a struct
+ * layout changes, so that a caller built against an older header can refuse to run instead of overrunning a buffer
+ * (round 5 grew ns_plan_gemm's out[6] to out[8]). */
+int ns_abi_version(void);
 int ns_plan_attention_split(int B, int S, int H, int dk);
 
 /* Measurement hook for bench.py's roofline legs: while enabled, the launches of the three heaviest kernels inside

@@ -49,6 +49,9 @@ SIGNATURES = {
     "ns_last_phase2_rows": (C.c_int64, [_P]),
     "ns_plan_gemm": (_I, [_I, _I, _I, _I, C.POINTER(C.c_int32)]),
     "ns_plan_row_tile": (_I, [_I, _I]),
+    "ns_plan_row_tile_k": (_I, [_I, _I, _I]),
+    "ns_acc_chunk": (_I, []),
+    "ns_abi_version": (_I, []),
     "ns_plan_attention_split": (_I, [_I, _I, _I, _I]),
     "ns_op_ws_bytes": (_Z, [_P, _I, _I]),
     "ns_op_mask_from_lengths": (_I, [_P, _I, _I, _P, _P]),

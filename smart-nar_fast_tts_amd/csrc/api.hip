@@ -75,7 +75,7 @@ static const char* kPredNames[3] = {"duration", "pitch", "energy"};
 // rule or a derived constant in the arena changes), the arena size and a hash of the configuration — so that bytes packed by
 // another build, for another configuration, or never finalized are refused instead of silently misread.
 constexpr uint32_t ARENA_MAGIC = 0x3246534eu;  // "NSF2"
-constexpr uint32_t ARENA_LAYOUT_VERSION = 5;   // 5: long position table; 4: header added (round 3's layout 3 grew the PostNet constants)
+constexpr uint32_t ARENA_LAYOUT_VERSION = 6;   // 6: config hash without the run-time switches (same offsets as 5, which hashed them); 5: long position table; 4: header added
 constexpr int ARENA_HDR_WORDS = 16;
 static void arena_header(const ns_model* m, uint32_t* w) {
   memset(w, 0, ARENA_HDR_WORDS * sizeof(uint32_t));
@@ -1168,10 +1168,15 @@ extern "C" int ns_plan_gemm(int M, int N, int Cin, int KW, int32_t out[8]) {
   if (out) for (int i = 0; i < 8; ++i) out[i] = planned ? o[i] : 0;
   return planned ? 1 : 0;
 }
-extern "C" int ns_plan_row_tile(int M, int N) {
-  if (M <= 0 || (N != 256 && N != 512)) return 0;
-  return conv_gemm_row_tile(M, N);
+extern "C" int ns_plan_row_tile_k(int M, int N, int K) {
+  if (M <= 0 || K <= 0 || (N != 256 && N != 512)) return 0;
+  return conv_gemm_row_tile(M, N, K);
 }
+// (the two-argument form answers for the shortest contraction a full-row GEMM of that width has: the attention output
+// projection, K = N)
+extern "C" int ns_plan_row_tile(int M, int N) { return ns_plan_row_tile_k(M, N, N); }
+extern "C" int ns_acc_chunk(void) { return conv_gemm_acc_chunk(); }
+extern "C" int ns_abi_version(void) { return NS_ABI_VERSION; }
 extern "C" int ns_plan_attention_split(int B, int S, int H, int dk) { return attention_split(B, S, H, dk); }
 
 extern "C" int ns_profile_enable(ns_model* m, int on) {

@@ -66,7 +66,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // MF for all of its rows (the two instructions walk k in different orders: lane group q of step e holds k = 16g + 4q + e
 // against 8g + 4h + e), so the rows of a launch — replicas of an utterance inside a batch — always carry the same bits.
 template <int BM, int BN, int BK, int KS, int WGM = 2, int WGN = 2, bool ROWEPI = false, int TICKET = 0, int MF = 32>  // TICKET: row width / 256, 0 = off
-__global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, int ntn) {
+__global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, int ntn, int fl) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type does not exist in the host pass; it only needs the stub
   constexpr int NW = WGM * WGN;       // waves per K-split group, arranged WGM x WGN over the block tile
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -87,6 +87,16 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
   static_assert(!ROWEPI || (KS == 1 && BN % 256 == 0 && (BM % EPR) % NW == 0 && (BM < EPR || EPR % NW == 0)), "row epilogue: every pass's rows divide over the waves");
   static_assert(!(ROWEPI && TICKET), "a full-row tile needs no ticket");
   using acc_t = typename std::conditional<MF == 32, f32x16, f32x4>::type;
+  // CHUNKED ACCUMULATION (round 6).  One accumulator that takes all K / 2 (MF 32) MFMA steps of a long contraction in sequence
+  // rounds every step against the whole running sum: the error of a row grows like sqrt(K) — measured against a float64
+  // evaluation the k=9 convolution (K = 2304) came out 3.8x, at K = 4608 5.1x, as far from the truth as torch's blocked CPU
+  // sums, while the K = 256 projections are level with them (profiles/r06_accuracy_vs_f64.md).  So a tile keeps TWO accumulator
+  // sets: `acc` takes `fl` K steps (fl * BK k values) starting from zero, then is added into `tot` and cleared; the partial sums
+  // the MFMAs round against stay short.  Error model (variance of a sequential sum ~ n^2, of c chunks of m steps ~ n (m + c)):
+  // K = 2304, chunks of 128: 3.7x smaller (measured: 3.9x at 128, 4.7x at 64 — the default, conv_gemm_acc_chunk).  Cost: TM*TN*NR more registers — tiles of up to 32 accumulator registers per lane
+  // have room (ACC2), the taller ones (144 ... 256 rows x 256) do not and are kept for K <= 256 only (plan_rows) — and NR * TM * TN
+  // adds per chunk next to fl * 4 * (BK / KG) * TM * TN MFMAs.  fl == 0 (NS_ACC_CHUNK=0, A/B runs): one sequential sum, as before.
+  constexpr bool ACC2 = TM * TN * NR <= 32;
 
   // Four DISTINCT LDS objects (not [2][...] arrays) and a 2x unrolled K loop with a static buffer index: hipcc tracks
   // in-flight LDS-DMA per LDS object, so a ds_read from As0 does not wait for a DMA that is filling As1.  With one
@@ -199,6 +209,15 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
       for (int r = 0; r < NR; ++r) acc[mi][ni][r] = 0.f;
+  [[maybe_unused]] acc_t tot[ACC2 ? TM : 1][ACC2 ? TN : 1];
+  if constexpr (ACC2) {
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) tot[mi][ni][r] = 0.f;
+  }
 
   // this lane's bias values (KS == 1 epilogues): requested now, consumed after the K loop (in the epilogue the load's
   // latency was fully exposed)
@@ -230,7 +249,11 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
   __syncthreads();
 
   // one step: prefetch this group's next chunk into the OTHER buffer pair, then 4*TM*TN*(BK/8) MFMAs on this one
-  auto step = [&](int st, const float* Ac, const float* Bc, float* An, float* Bn) {
+  // FRESH (a compile-time tag): the step opens an accumulation chunk — its first MFMA of every tile takes C = 0 (an inline
+  // constant: no register clearing) instead of the previous chunk's sum, which the caller has just added into `tot`
+  auto step = [&](auto fresh_c, int st, const float* Ac, const float* Bc, float* An, float* Bn) {
+    constexpr bool FRESH = decltype(fresh_c)::value;
+    const acc_t zero = {};
     const int ch = st * KS + grp;
     if (ch + KS < nch) dma_chunk(An, Bn, ch + KS);
     if (KS == 1 || ch < nch) {
@@ -250,7 +273,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
               for (int ni = 0; ni < TN; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], (FRESH && g == 0 && e == 0) ? zero : acc[mi][ni], 0, 0, 0);
         } else {
           // 16-row family: the B fragments of the wave's columns once, then one A slab at a time (a tall column-split tile has
           // up to 16 of them: all A fragments live at once would be 64 registers).  Every accumulator still sees its k values
@@ -265,16 +288,45 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
             for (int e = 0; e < 4; ++e)
 #pragma unroll
               for (int ni = 0; ni < TN; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[ni][e], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[ni][e], (FRESH && g == 0 && e == 0) ? zero : acc[mi][ni], 0, 0, 0);
           }
         }
       }
+    } else if constexpr (FRESH) {  // (a K group with no chunk left at this step: its accumulators were flushed, they restart from zero)
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = zero;
     }
     __syncthreads();  // drains this step's DMA (vmcnt) and fences the buffer swap
   };
+  // (fl is even or 0: a chunk ends behind the second step of a pair.  The last chunk is not flushed here: `acc` goes into the
+  // epilogue as tot + acc — for a contraction of one chunk that is 0 + acc, the same bits as the sequential sum.)
+  int due = fl;
+  bool fresh = false;
+  constexpr std::false_type CONT{};
+  constexpr std::true_type OPEN{};
   for (int st = 0; st < nsteps; st += 2) {
-    step(st, A0, B0, A1, B1);
-    if (st + 1 < nsteps) step(st + 1, A1, B1, A0, B0);
+    if (ACC2 && fresh) step(OPEN, st, A0, B0, A1, B1);
+    else step(CONT, st, A0, B0, A1, B1);
+    if (st + 1 < nsteps) step(CONT, st + 1, A1, B1, A0, B0);
+    if constexpr (ACC2) {
+      due -= 2;
+      fresh = due == 0 && st + 2 < nsteps;
+      if (fresh) {
+        due = fl;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni) tot[mi][ni] += acc[mi][ni];
+      }
+    }
+  }
+  if constexpr (ACC2) {
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = tot[mi][ni] + acc[mi][ni];
   }
 
   // C/D layout: 32x32 tile — col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), r < 16; 16x16 tile — col = lane & 15, row = r + 4 (lane >> 4), r < 4
@@ -462,13 +514,32 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
 #endif
 }
 
+// k values per accumulation chunk (see ACC2 in the kernel): 64 by default; NS_ACC_CHUNK=<multiple of 64> or 0 (off) for A/B runs.
+// Measured (profiles/r06_accuracy_vs_f64*.md, profiles/r06_acc_chunk_ab.txt): distance from a float64 evaluation relative to the fp32
+// reference's own, worst quantity (pitch / energy, config 2 and 4) 3.75x with one sequential sum, 1.71x with chunks of 128, 1.04x
+// with chunks of 64; a forward costs +1.0 ... 1.8 % with chunks of 64 (of which 0.3 % over chunks of 128, the rest is the 256 x 256
+// tile giving way to 128 x 256).
+int conv_gemm_acc_chunk() {
+  static const int v = [] {
+    const char* e = getenv("NS_ACC_CHUNK");
+    int k = e ? atoi(e) : 64;
+    if (k < 0 || k % 64 != 0) k = 64;
+    return k;
+  }();
+  return v;
+}
+static int acc_chunk_k() { return conv_gemm_acc_chunk(); }
+// a tile with room for the second accumulator set: <= 32 accumulator registers per lane
+static constexpr bool tile_chunks(int bm, int bn, int waves) { return bm * bn / (64 * waves) <= 32; }
+
 template <int BM, int BN, int BK, int KS = 1, int WGM = 2, int WGN = 2, bool ROWEPI = false, int TICKET = 0, int MF = 32>
 static hipError_t launch_t(const ConvGemm& p, hipStream_t st, const LaunchTiming* tm = nullptr) {
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  const int fl = ((acc_chunk_k() / BK) + 1) & ~1;  // K steps per accumulation chunk, even (0: off)
   if (tm && (tm->start || tm->stop))  // the events ride on this kernel's own dispatch packet (kernels.h LaunchTiming)
-    hipExtLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN, ROWEPI, TICKET, MF>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, tm->start, tm->stop, 0, p, ntn);
+    hipExtLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN, ROWEPI, TICKET, MF>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, tm->start, tm->stop, 0, p, ntn, fl);
   else
-    hipLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN, ROWEPI, TICKET, MF>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, p, ntn);
+    hipLaunchKernelGGL((k_conv_gemm<BM, BN, BK, KS, WGM, WGN, ROWEPI, TICKET, MF>), dim3(ntm * ntn), dim3(64 * WGM * WGN * KS), 0, st, p, ntn, fl);
   return hipGetLastError();
 }
 
@@ -612,7 +683,11 @@ static RowPlan plan_rows(long M, int N, int chunks) {
   // short contractions (QKV, fc: K = d, 8-16 chunks): prologue and epilogue weigh as much as the K loop, and three 64x128 workgroups
   // per CU interleave them better than one tall 16-wave tile — settled by forward A/B in round 3 (config 2 5.476 -> 5.456 ms) and
   // again by the model's own margin in round 4 (B = 20 QKV: 256x256 one step 83 us in the lab against 77 us on 64x128)
-  const int first = chunks <= 16 ? T64W : T256;
+  // long contractions (K > 256) stay on the tiles that accumulate in chunks (k_conv_gemm ACC2): 128 x 256 and below — the 256 x 256
+  // tile's 64 accumulator registers per lane leave no room for the second set.  (Round 5 ran the decoder's k=9 GEMM on it at
+  // B = 16: 543 us per launch against 554 on two rounds of 128 x 256 — 0.8 % of a forward for 3.7x less rounding error.)
+  const bool long_k = chunks > 8 && acc_chunk_k() > 0;
+  const int first = chunks <= 16 ? T64W : long_k ? T128 : T256;
   for (int t = first; t < N_TILES; ++t) {
     if (kTile[t].bn > N && t != T32 && t != T64N && t != T64) continue;  // (a 256-wide tile on a narrower output: never)
     const float c = tile_time(t, M, N, chunks);
@@ -645,13 +720,15 @@ static RowPlan plan_rows(long M, int N, int chunks) {
       const long w = tile_wgs(best.rem.id, M, N);  // balance over the 256 CUs (co-resident workgroups share a CU's matrix pipe)
       if ((double)w / (double)(((w + 255) / 256) * 256) >= 0.9) margin = 1.03f;
     }
+    // (16 s x 256 on 16 waves and 16 s x 128 on 8: 4 s accumulator registers per lane — s <= 8 has room for the second set)
+    const int w_max = long_k ? 8 : F16W_MAX, n_max = long_k ? 8 : F16N_MAX;
     if (N % 256 == 0)
-      for (int sl = F16W_MIN; sl <= F16W_MAX; ++sl) {
+      for (int sl = F16W_MIN; sl <= w_max; ++sl) {
         const float c = tile16_time(F16W, sl, M, N, chunks) * margin;
         if (c < best.us) best = RowPlan{{F32, -1}, 0, {F16W, sl}, c};
       }
     if (N % 128 == 0 && tile16n_enabled())
-      for (int sl = F16N_MIN; sl <= F16N_MAX; ++sl) {
+      for (int sl = F16N_MIN; sl <= n_max; ++sl) {
         const float c = tile16_time(F16N, sl, M, N, chunks) * margin;
         if (c < best.us) best = RowPlan{{F32, -1}, 0, {F16N, sl}, c};
       }
@@ -679,12 +756,16 @@ bool conv_gemm_plan(int M, int N, int Cin, int KW, int out[8]) {
 // for 35.5 — so the height is the multiple of 16 that gives the fullest CU the fewest rows, BM x ceil(row tiles / 256); ties keep
 // the 32-row tile (MF 32) the BASELINE configurations were settled on.  Lab (us): w_2 + LN M = 9090 75 -> 60 (48 rows), M = 17 170
 // 117 -> 98 (80 rows); fc + LN 26.8 -> 22.4, 40.3 -> 35.1; predictor conv + LN 59 -> 47.5, 92 -> 76.5; M = 16 160 unchanged (64 = 2 x 32).
-int conv_gemm_row_tile(int M, int N) {
+int conv_gemm_row_tile(int M, int N, int K) {
   if (!launch_planner_enabled() || !tile16_enabled()) return 32;
-  (void)N;  // (256 and 512 columns take the same heights; at 512 the two B staging buffers alone are 128 KB of the CU's 160: 112 rows fit)
+  // (256 and 512 columns take the same heights; at 512 the two B staging buffers alone are 128 KB of the CU's 160: 112 rows fit)
+  // long contractions (K > 256: FFN w_2, the predictors' convolutions) keep to the heights with room for the second accumulator
+  // set (k_conv_gemm ACC2: BM * N / 1024 <= 32 registers per lane): all of them at 256 columns, 32 and 48 rows at 512
+  const int top = N > 256 ? 48 : 112;  // (N = 512: K >= 512 always — the attention output projection contracts over d = N)
+  (void)K;
   long best = 32 * ((((long)M + 31) / 32 + 255) / 256);
   int bm = 32;
-  for (int c = 48; c <= 112; c += 32) {  // 48, 80, 112: the odd multiples of 16 — an even one only ever ties rounds of the 32-row tile
+  for (int c = 48; c <= top; c += 32) {  // 48, 80, 112: the odd multiples of 16 — an even one only ever ties rounds of the 32-row tile
     const long rows = (long)c * ((((long)M + c - 1) / c + 255) / 256);
     if (rows < best) { best = rows; bm = c; }
   }
@@ -727,7 +808,7 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
     if (!conv_gemm_row_epilogue_ok(p.M, p.N, p.Cin) || (p.epi == EPI_LN && p.ldy != p.N) || (p.resid && (p.ldr & 3))) return hipErrorInvalidValue;
     // (the height follows the row count: conv_gemm_row_tile above; 16 waves side by side in the 16-row family)
     // (the heights the rule can pick: a 64- / 96- / 128-row tile only ever TIES two / three / four rounds of the 32-row one)
-    const int bm = conv_gemm_row_tile(p.M, p.N);
+    const int bm = conv_gemm_row_tile(p.M, p.N, p.KW * p.Cin);
     if (p.N == 256) {
       switch (bm) {
         case 48: return launch_t<48, 256, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
@@ -736,12 +817,10 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
         default: return launch_t<32, 256, 32, 1, 1, 8, true>(p, st, tm);
       }
     }
-    switch (bm) {
-      case 48: return launch_t<48, 512, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
-      case 80: return launch_t<80, 512, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
-      case 112: return launch_t<112, 512, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
-      default: return launch_t<32, 512, 32, 1, 1, 16, true>(p, st, tm);
-    }
+    // (512 columns: 32 or 48 rows.  The 80- and 112-row forms of round 5 held 40 / 56 accumulator registers per lane — no room for
+    //  the second accumulator set — and every 512-wide full-row GEMM contracts over K >= 512, so the rule never picks them.)
+    if (bm == 48) return launch_t<48, 512, 32, 1, 1, 16, true, 0, 16>(p, st, tm);
+    return launch_t<32, 512, 32, 1, 1, 16, true>(p, st, tm);
   }
   const bool bk32 = (p.Cin % 32) == 0;
   // Tile / wave-grid choice (tools/lab sweeps on the path's shapes, MI355X, same-run comparisons).  What wins is

@@ -75,7 +75,8 @@ hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st, const LaunchTimin
 // the cost model's estimate in us
 bool conv_gemm_plan(int M, int N, int Cin, int KW, int out[8]);
 bool conv_gemm_tile16_enabled();  // the 16-row tile family is in use (planner on, NS_TILE16 != 0)
-int conv_gemm_row_tile(int M, int N);  // height of the full-row (LayerNorm epilogue) tile for M rows of N = 256 / 512 columns
+int conv_gemm_row_tile(int M, int N, int K = 256);  // height of the full-row (LayerNorm epilogue) tile for M rows of N = 256 / 512 columns, contraction length K
+int conv_gemm_acc_chunk();  // k values per accumulation chunk of the long contractions (gemm_conv.hip ACC2; NS_ACC_CHUNK, 0 = one sequential sum)
 // NS_PLAN=0 in the environment: the round-3 one-tile-per-launch rules (A/B runs of the planner; read once)
 bool launch_planner_enabled();
 // opt-in "bf16x3" precision mode (gemm_bf16x3.hip): same contraction from an exact 3-way bf16 split of both operands

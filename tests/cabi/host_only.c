@@ -14,6 +14,7 @@ typedef size_t (*arena_fn)(const ns_model*);
 typedef size_t (*ws_fn)(const ns_model*, int, int);
 typedef int (*plan_fn)(int, int, int, int, int32_t*);
 typedef int (*split_fn)(int, int, int, int);
+typedef int (*version_fn)(void);
 
 int main(int argc, char** argv) {
   void* so;
@@ -25,7 +26,7 @@ int main(int argc, char** argv) {
   if (!so) { printf("dlopen: %s\n", dlerror()); return 3; }
   {
     /* (POSIX idiom: ISO C has no conversion from void* to a function pointer) */
-    last_error_fn last_error; create_fn create; destroy_fn destroy; arena_fn arena; ws_fn enc_ws; plan_fn plan_gemm; split_fn att_split;
+    last_error_fn last_error; create_fn create; destroy_fn destroy; arena_fn arena; ws_fn enc_ws; plan_fn plan_gemm; split_fn att_split; version_fn abi_version;
     *(void**)(&last_error) = dlsym(so, "ns_last_error");
     *(void**)(&create) = dlsym(so, "ns_create");
     *(void**)(&destroy) = dlsym(so, "ns_destroy");
@@ -33,6 +34,9 @@ int main(int argc, char** argv) {
     *(void**)(&enc_ws) = dlsym(so, "ns_encoder_ws_bytes");
     *(void**)(&plan_gemm) = dlsym(so, "ns_plan_gemm");
     *(void**)(&att_split) = dlsym(so, "ns_plan_attention_split");
+    *(void**)(&abi_version) = dlsym(so, "ns_abi_version");
+    /* a caller built against this header refuses a library with another contract (round 5 grew ns_plan_gemm's out[] unversioned) */
+    if (!abi_version || abi_version() != NS_ABI_VERSION) { printf("ABI version mismatch\n"); return 10; }
     if (!last_error || !create || !destroy || !arena || !enc_ws || !plan_gemm || !att_split) { printf("missing symbol\n"); return 4; }
     memset(&c, 0, sizeof(c));
     c.n_vocab = 361; c.max_seq_len = 1000;
@@ -47,7 +51,7 @@ int main(int argc, char** argv) {
     if (arena(m) < 100u * 1000u * 1000u) return 6;
     c.d_dec = 512; /* encoder_hidden != decoder_hidden: refused with a message */
     { ns_model* bad = 0; if (create(&c, &bad) == 0 || strlen(last_error()) == 0) return 7; }
-    if (plan_gemm(16160, 1024, 256, 9, plan) != 1 || plan[0] != 256 || plan[1] != 256 || plan[2] != 16160 || plan[5] != 0 || plan[6] != 32 || plan[7] <= 0) return 8;
+    if (plan_gemm(16160, 1024, 256, 9, plan) != 1 || plan[0] != 128 || plan[1] != 256 || plan[2] != 16160 || plan[5] != 0 || plan[6] != 32 || plan[7] <= 0) return 8;
     if (att_split(16, 1010, 2, 128) != 1) return 9;
     destroy(m);
   }

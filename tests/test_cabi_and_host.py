@@ -426,11 +426,12 @@ def test_launch_plan_invariants_and_settled_choices(lib):
                 assert ((M + 63) // 64) * ((N + 127) // 128) <= 256, (M, N)
                 continue
             assert rows + rrows == M and mf in (16, 32) and us > 0 and bn in (64, 128, 256), (M, N, bm, bn)
+            long_k = Cin * KW > 256  # long contractions keep to the tiles with the second accumulator set (<= 32 registers per lane)
             if mf == 16:  # the 16-row family: ONE launch, any multiple of 16 rows per tile, 128 or 256 columns
                 fam16 += 1
-                assert rrows == 0 and bm % 16 == 0 and 48 <= bm <= 256 and bn in (128, 256) and N % bn == 0, (M, N, bm, bn)
+                assert rrows == 0 and bm % 16 == 0 and 48 <= bm <= (128 if long_k else 256) and bn in (128, 256) and N % bn == 0, (M, N, bm, bn)
                 continue
-            assert bm in (32, 64, 128, 256), (M, N, bm, bn)
+            assert bm in (32, 64, 128) + (() if long_k else (256,)), (M, N, bm, bn)
             if rrows:
                 ntn = -(-N // bn)
                 per = (256 // ntn) * bm  # rows of one full step of the main tile
@@ -438,22 +439,27 @@ def test_launch_plan_invariants_and_settled_choices(lib):
             if Cin * KW <= 512:
                 assert bm <= 64, ("short contractions stay on the 8-wave tiles", M, N, bm, bn)
     assert fam16 > 50, fam16  # between the steps of the tall tiles the family is what the plan picks
-    # BASELINE configurations (B*T_pad rows): config 2, config 5, config 4 — settled by forward A/B runs, unchanged by the 16-row family
-    assert plan(16160, 1024, 256, 9)[1][:7] == [256, 256, 16160, 0, 0, 0, 32]      # FFN w_1: one round of the 256x256 tile
+    assert lib.ns_abi_version() == 6 and lib.ns_acc_chunk() == 64
+    # BASELINE configurations (B*T_pad rows): config 2, config 5, config 4.  Round 6: the k=9 / k=5 contractions accumulate in
+    # chunks, which needs a second accumulator set — the 256x256 tile (64 registers per lane) has no room, two rounds of 128x256 do
+    assert plan(16160, 1024, 256, 9)[1][:7] == [128, 256, 16160, 0, 0, 0, 32]      # FFN w_1: two rounds of the 128x256 tile
     assert plan(16160, 512, 512, 5)[1][:7] == [128, 256, 16160, 0, 0, 0, 32]       # PostNet 512->512: one round of 128x256
-    assert plan(16160, 768, 256, 1)[1][:7] == [192, 256, 16160, 0, 0, 0, 16]       # QKV: one step of 255 tall tiles (forward trace: 59.6-60.6 us against 61.0-61.9 on 64x128)
-    assert plan(31248, 1024, 256, 9)[1][:7] == [256, 256, 31248, 0, 0, 0, 32]      # config 5: two rounds
-    ok, p4 = plan(66624, 1024, 512, 9)                                       # config 4: four full rounds + the remaining 1088 rows
-    assert ok and p4[:3] == [256, 256, 65536] and p4[5] == 1088 and p4[3] <= 64
-    # between the steps (B = 9, 11 utterances of 1010 frames; the ragged config-2 batch's packed rows): one launch of a tile as tall as
-    # the rows ask for — 9090 rows x 4 column tiles = 64 row tiles of 144 rows = 256 workgroups
-    assert plan(9090, 1024, 256, 9)[1][:7] == [144, 256, 9090, 0, 0, 0, 16]
-    assert plan(11110, 1024, 256, 9)[1][:7] == [176, 256, 11110, 0, 0, 0, 16]
+    assert plan(16160, 768, 256, 1)[1][:7] == [192, 256, 16160, 0, 0, 0, 16]       # QKV (K = 256, one chunk: the tall tiles stay): one step of 255 tall tiles
+    assert plan(31248, 1024, 256, 9)[1][:7] == [128, 256, 31248, 0, 0, 0, 32]      # config 5: four rounds
+    ok, p4 = plan(66624, 1024, 512, 9)                                       # config 4: many rounds of a tile of at most 128 rows
+    assert ok and p4[0] <= 128 and p4[1] == 256 and p4[2] + p4[5] == 66624
+    # between the steps (B = 9, 10 utterances of 1010 frames; the ragged config-2 batch's packed rows): one launch of a tile as tall as
+    # the rows ask for, at most 128 rows — 9090 rows x 4 column tiles = 190 row tiles of 48 rows = 3 per CU
+    assert plan(9090, 1024, 256, 9)[1][:7] == [48, 256, 9090, 0, 0, 0, 16]
+    assert plan(10100, 1024, 256, 9)[1][:7] == [80, 256, 10100, 0, 0, 0, 16]
     assert plan(10490, 1024, 256, 9)[1][6] == 16 and plan(9090, 512, 512, 5)[1][6] == 16
-    # the full-row (GEMM + LayerNorm epilogue) tile: as tall as the fullest CU needs, 32 on ties
+    # the full-row (GEMM + LayerNorm epilogue) tile: as tall as the fullest CU needs, 32 on ties; 512 columns: 32 or 48 rows only
+    # (every 512-wide full-row GEMM contracts over K >= 512, and the taller 512-column tiles have no room for the second set)
     rt = {M: lib.ns_plan_row_tile(M, 256) for M in (8080, 9090, 10490, 11110, 12120, 16160, 17170, 20200, 31248)}
     assert rt == {8080: 32, 9090: 48, 10490: 48, 11110: 48, 12120: 48, 16160: 32, 17170: 80, 20200: 80, 31248: 32}, rt
+    assert all(lib.ns_plan_row_tile_k(M, 256, 1024) == v for M, v in rt.items())
     assert lib.ns_plan_row_tile(66624, 512) == 32 and lib.ns_plan_row_tile(9090, 512) == 48 and lib.ns_plan_row_tile(9090, 300) == 0
+    assert lib.ns_plan_row_tile(17170, 512) == 32 and lib.ns_plan_row_tile_k(25250, 512, 1024) == 32
     # "time follows the rows": the model's cost per utterance for the dominant launch never jumps by more than 6 % from B to B + 1
     # utterances of 1010 frames (round 4's plans: +19 % at B = 8 -> 9, +16 % at 16 -> 17 in the measured forward), and it is
     # monotone in the rows up to one microsecond of rounding
