@@ -1235,7 +1235,8 @@ def test_bits_across_launch_plans():
     with identical integers.  This test pins that statement: seven utterances (padded in every batch, like F3c's) alone in a batch
     of 8, inside a batch of 9 and inside a batch of 17 (MF 32 <-> 16, one launch <-> cut), with src_lens on the device (dense rows)
     and on the host (packed rows): durations / frame counts identical, bucket decisions pinned, |delta mel| within the bound
-    measured on the round-6 build (2.1e-6 mel / 4.3e-6 pitch-relative) x 2 — and replicas INSIDE one batch stay bit-identical
+    measured on the round-6 build (mel 1.0e-6, PostNet mel 1.1e-6, pitch 6.1e-6 and energy 7.4e-6 relative on the in-range
+    frames, log-duration 2.4e-7) x 2 — and replicas INSIDE one batch stay bit-identical
     (test_large_batch_replicas_are_identical).  INTEGRATION.md 'Bits and batch size' states the same for callers."""
     import smart_nar_fast_tts_amd.workload as wl
     from oracle import parity
@@ -1283,17 +1284,20 @@ def test_bits_across_launch_plans():
                     t = int(mel_lens[i])
                     for key, k in (("mel", 0), ("postnet", 1)):
                         worst[key] = max(worst[key], float((out[k][i, :t] - base[k][i, :t]).abs().max()))
-                    for key, k in (("pitch_rel", 2), ("energy_rel", 3)):
-                        a, b = out[k][i, :t].double(), base[k][i, :t].double()
-                        worst[key] = max(worst[key], float(((a - b).abs() / b.abs().clamp(min=1.0)).max()))
+                    # (pitch / energy: on the frames inside the bin range, relative — the quantity a bucket decision hangs on,
+                    # oracle/parity.py; near zero the predictor's output is a cancelling sum whose absolute noise is that of its
+                    # +-500 summands)
+                    for key, k, bins in (("pitch_rel", 2, "variance_adaptor.pitch_bins"), ("energy_rel", 3, "variance_adaptor.energy_bins")):
+                        worst[key] = max(worst[key], parity.max_rel_deviation(out[k][i, :t].cpu().numpy(), base[k][i, :t].cpu().numpy(),
+                                                                              np.asarray(sd[bins]), np.ones(t, dtype=bool)))
                     s = int(ln[i])
                     worst["log_d"] = max(worst["log_d"], float((out[4][i, :s] - base[4][i, :s]).abs().max()))
         print("launch plans of the decoder k=9 GEMM (rows on the grid, plan) and phase-2 rows:", plans)
         print("the same seven utterances in batches of 8 / 9 / 17, device + dense vs host + packed lengths, worst difference:", worst)
         mfs = {p[0]["mfma_edge"] for p in plans.values() if p[0]}
         assert len({(p[0] or {}).get("main") for p in plans.values()}) > 1, "the three batch sizes were meant to take different plans"
-        assert worst["mel"] <= 5e-6 and worst["postnet"] <= 5e-6 and worst["log_d"] <= 2e-6, worst
-        assert worst["pitch_rel"] <= 1e-5 and worst["energy_rel"] <= 1e-5, worst
+        assert worst["mel"] <= 2.5e-6 and worst["postnet"] <= 2.5e-6 and worst["log_d"] <= 6e-7, worst
+        assert worst["pitch_rel"] <= 1.5e-5 and worst["energy_rel"] <= 1.5e-5, worst
         print("MFMA tile edges seen:", mfs)
     finally:
         m.packed_rows = keep
