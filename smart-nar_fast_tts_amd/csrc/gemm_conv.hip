@@ -407,8 +407,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
       lng[i] = *reinterpret_cast<const f32x4*>(p.e.ln_g + lane * 4 + i * 256);
       lnb[i] = *reinterpret_cast<const f32x4*>(p.e.ln_b + lane * 4 + i * 256);
     }
-    RowEpilogue e2 = p.e;
-    e2.y_out = p.Y;  // (ldy == BN: checked by the launcher)
+    const RowEpilogue& e2 = p.e;  // (y_out == Y, ldy == BN: set / checked by the launcher — a modified copy of the struct kept all of its
+                                  //  ~25 pointers live in SGPRs across the unrolled passes: 36-43 spilled SGPRs in the two-pass tiles, round 5)
     auto pass = [&](auto pc) {
       constexpr int P = decltype(pc)::value;
       constexpr int P0 = P * EPR, PR = (BM - P0 < EPR ? BM - P0 : EPR), RPW = PR / NW;
@@ -427,8 +427,14 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
         }
       }
       int tt[RPW];
-      bool masked[RPW];
-      row_batch_masks<RPW>(p.e, p.M, p.S, mw, 1, tt, masked);
+      unsigned keep[RPW];
+      // the rows of a wave are wave-uniform, so left to itself the compiler keeps every row's utterance index, position, 64-bit
+      // length and mask bit in SGPRs — 4 rows x 6 scalars on top of the kernel's ~25 argument pointers: 36-43 spilled SGPRs in
+      // the two-pass tiles (round 5).  Handing the first row over as a VGPR value makes the lookups vector loads and the row
+      // addresses vector arithmetic; the mask is a keep word (rowln.h keep_or_zero): same values, no scalar pressure.
+      int mv = mw;
+      asm("" : "+v"(mv));
+      row_batch_masks<RPW>(p.e, p.M, p.S, mv, 1, tt, keep);
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) {
         const int nl = wn0 + ni * MF + ecol;
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_conv_gemm(ConvGemm p, i
           v[rr][i] = *reinterpret_cast<const f32x4*>(trow(wid * RPW + rr) + lane * 4 + i * 256);
           if (p.resid) v[rr][i] += rv[rr][i];
         }
-      row_batch_finish<NV, RPW>(v, tt, masked, lane, p.epi, e2, p.M, mw, 1, lng, lnb);
+      row_batch_finish<NV, RPW>(v, tt, keep, lane, p.epi, e2, p.M, mv, 1, lng, lnb);
     };
     pass(std::integral_constant<int, 0>{});
     if constexpr (NPASS > 1) pass(std::integral_constant<int, 1>{});
@@ -806,6 +812,7 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
   if (p.epi != EPI_NONE) {
     // full-row tile: BM rows x N columns, the waves side by side (32 rows: N / 32 waves with one 32x32 MFMA tile each)
     if (!conv_gemm_row_epilogue_ok(p.M, p.N, p.Cin) || (p.epi == EPI_LN && p.ldy != p.N) || (p.resid && (p.ldr & 3))) return hipErrorInvalidValue;
+    p.e.y_out = p.Y;  // the full-row tile's LayerNorm rows go straight to Y (the ticketed form above keeps raw rows in Y and y_out apart)
     // (the height follows the row count: conv_gemm_row_tile above; 16 waves side by side in the 16-row family)
     // (the heights the rule can pick: a 64- / 96- / 128-row tile only ever TIES two / three / four rounds of the 32-row one)
     const int bm = conv_gemm_row_tile(p.M, p.N, p.KW * p.Cin);

@@ -55,7 +55,9 @@ __device__ __forceinline__ float ln_affine(float v, float mean, float rstd, floa
 __device__ __forceinline__ int wave_bucketize(const float* __restrict__ bins, int n_edges, float v, int lane) {
   int cnt = 0;
   for (int k = lane; k < n_edges; k += 64) cnt += !(bins[k] >= v) ? 1 : 0;
-  return wave_sum(cnt);
+  int idx = wave_sum(cnt);
+  asm("" : "+v"(idx));  // (wave_sum ends in v_readlane: as a VGPR value the embedding row's address is not 64-bit SGPR arithmetic per row)
+  return idx;
 }
 
 // mean / rstd of one row held as up to NV float4 per lane (column c = lane*4 + i*256; entries at c >= C must be zero).
@@ -111,8 +113,12 @@ __device__ __forceinline__ void ln_store(const f32x4 (&v)[NV], int C, int lane, 
 // 2.11e-5 (pitch / energy) with the float64 tail against 2.28e-5 / 2.12e-5 with this fp32 one — the deviation is set by the
 // fp32 summation order of the contractions upstream, not by these 256-term sums.  profiles/r03_bucket_edge_deviation.md.)
 // value part: pred[m] (returned too)
+// masked_fill as a bit mask: keep = 0xFFFFFFFF for a valid row, 0 for a padded one; x & keep is x or +0.0 — the bits of `masked ? 0.f : x`
+// without a lane predicate per row (an SGPR pair each: eight rows per wave in the ticketed epilogue spilled scalar registers, round 5)
+__device__ __forceinline__ float keep_or_zero(float x, unsigned keep) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & keep); }
+
 template <int NV>
-__device__ __forceinline__ float predictor_row_value(const f32x4 (&v)[NV], int C, int lane, const RowEpilogue& e, int m, bool masked, bool store = true) {
+__device__ __forceinline__ float predictor_row_value(const f32x4 (&v)[NV], int C, int lane, const RowEpilogue& e, int m, unsigned keep, bool store = true) {
 #pragma clang fp contract(off)
   float mean, rstd;
   ln_moments<NV>(v, C, lane, mean, rstd);
@@ -129,7 +135,7 @@ __device__ __forceinline__ float predictor_row_value(const f32x4 (&v)[NV], int C
     }
   }
   float pv = wave_sum(dot) + e.blin[0];
-  if (masked) pv = 0.f;
+  pv = keep_or_zero(pv, keep);
   // model/modules.py:82-89: with a target the embedding comes from bucketize(target) and the prediction is returned
   // unscaled; without one prediction = prediction * control and the embedding comes from the scaled prediction
   if (e.target == nullptr) pv *= e.control;
@@ -140,7 +146,7 @@ __device__ __forceinline__ float predictor_row_value(const f32x4 (&v)[NV], int C
 template <int NV>
 __device__ __forceinline__ void predictor_row_tail(const f32x4 (&v)[NV], int C, int lane, float /*mean*/, float /*rstd*/, const RowEpilogue& e,
                                                    int m, int t, bool masked) {
-  const float pv = predictor_row_value<NV>(v, C, lane, e, m, masked);
+  const float pv = predictor_row_value<NV>(v, C, lane, e, m, masked ? 0u : 0xFFFFFFFFu);
   if (e.emb == nullptr) return;
   const int cnt = wave_bucketize(e.bins, e.n_edges, e.target ? e.target[m] : pv, lane);
   const float* er = e.emb + (size_t)cnt * e.D;
@@ -166,7 +172,7 @@ typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
 // second half of a batched row epilogue: R rows already in registers (v[j] = act(contraction + bias) + resid of row
 // m_first + j * m_step; masked[j] / tt[j] = its mask bit and position), LayerNorm affine of this lane's columns in lng / lnb
 template <int NV, int R>
-__device__ __forceinline__ void row_batch_finish(f32x4 (&v)[R][NV], const int (&tt)[R], const bool (&masked)[R], int lane, int epi, const RowEpilogue& e,
+__device__ __forceinline__ void row_batch_finish(f32x4 (&v)[R][NV], const int (&tt)[R], const unsigned (&keep)[R], int lane, int epi, const RowEpilogue& e,
                                                  int M, int m_first, int m_step, const f32x4 (&lng)[NV], const f32x4 (&lnb)[NV]) {
   constexpr int C = NV * 256;
   if (epi == EPI_LN) {
@@ -177,7 +183,7 @@ __device__ __forceinline__ void row_batch_finish(f32x4 (&v)[R][NV], const int (&
 #pragma unroll
       for (int i = 0; i < NV; ++i)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[j][i][k] = masked[j] ? 0.f : ln_affine(v[j][i][k], mean, rstd, lng[i][k], lnb[i][k]);  // ln_store's expression; masked_fill(mask, 0)
+        for (int k = 0; k < 4; ++k) v[j][i][k] = keep_or_zero(ln_affine(v[j][i][k], mean, rstd, lng[i][k], lnb[i][k]), keep[j]);  // ln_store's expression; masked_fill(mask, 0)
     }
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -193,7 +199,7 @@ __device__ __forceinline__ void row_batch_finish(f32x4 (&v)[R][NV], const int (&
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int m = m_first + j * m_step, mc = m < M ? m : M - 1;
-    const float pv = predictor_row_value<NV>(v[j], C, lane, e, mc, masked[j], m < M);  // (a row past M computes on whatever its registers hold and stores nothing)
+    const float pv = predictor_row_value<NV>(v[j], C, lane, e, mc, keep[j], m < M);  // (a row past M computes on whatever its registers hold and stores nothing)
     cnt[j] = e.emb ? wave_bucketize(e.bins, e.n_edges, e.target ? e.target[mc] : pv, lane) : 0;
   }
   if (e.emb == nullptr) return;
@@ -216,9 +222,9 @@ __device__ __forceinline__ void row_batch_finish(f32x4 (&v)[R][NV], const int (&
   }
 }
 
-// positions and mask bits of R rows (rows past M take row M-1's): the lens loads of all rows issued together
+// positions and keep words (0 = padded row, see keep_or_zero) of R rows (rows past M take row M-1's): the lens loads of all rows issued together
 template <int R>
-__device__ __forceinline__ void row_batch_masks(const RowEpilogue& e, int M, int S, int m_first, int m_step, int (&tt)[R], bool (&masked)[R]) {
+__device__ __forceinline__ void row_batch_masks(const RowEpilogue& e, int M, int S, int m_first, int m_step, int (&tt)[R], unsigned (&keep)[R]) {
   int bb_[R];
   long long ln[R];
 #pragma unroll
@@ -240,7 +246,10 @@ __device__ __forceinline__ void row_batch_masks(const RowEpilogue& e, int M, int
     for (int j = 0; j < R; ++j) ln[j] = 0x7fffffffffffffffll;
   }
 #pragma unroll
-  for (int j = 0; j < R; ++j) masked[j] = (long long)tt[j] >= ln[j];
+  for (int j = 0; j < R; ++j) {
+    keep[j] = (long long)tt[j] >= ln[j] ? 0u : 0xFFFFFFFFu;
+    asm("" : "+v"(keep[j]));  // (a VGPR word from here on, not a predicate the compiler may re-derive and hold)
+  }
 }
 
 // ticketed form: the rows come from memory (`rs`: descriptor over raw [M, ldraw]) through sc1 loads, see above
@@ -262,9 +271,9 @@ __device__ __forceinline__ void row_epilogue_batch(__amdgpu_buffer_rsrc_t rs, in
       v[j][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (mc * ldraw + lane * 4 + i * 256) * 4, 0, 16 /* sc1 */));
   }
   int tt[R];
-  bool masked[R];
-  row_batch_masks<R>(e, M, S, m_first, m_step, tt, masked);
-  row_batch_finish<NV, R>(v, tt, masked, lane, epi, e, M, m_first, m_step, lng, lnb);
+  unsigned keep[R];
+  row_batch_masks<R>(e, M, S, m_first, m_step, tt, keep);
+  row_batch_finish<NV, R>(v, tt, keep, lane, epi, e, M, m_first, m_step, lng, lnb);
 }
 
 }  // namespace ns

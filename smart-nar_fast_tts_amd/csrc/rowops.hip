@@ -730,27 +730,34 @@ __global__ __launch_bounds__(256) void k_gauss_upsample(const float* __restrict_
       __syncthreads();
       const float* arow = wt + (lane & 31) * (GU_LC + 1) + (lane >> 5);
       const float* xrow = x + ((size_t)b * L + lc + (lane >> 5)) * D + (lane & 31);
+      // (this wave's tiles are nbase + wv + 4 j, j < njt: ONE scalar count instead of four per-tile range predicates and
+      //  channel-range masks kept live across the loop — with expf's constants that was 18 spilled SGPRs, round 5)
+      const int njt = min(4, (nt - nbase - wv + 3) >> 2);
+      const int col = (nbase + wv) * 32 + (lane & 31);  // channel of tile j: col + 128 j
       for (int l2 = 0; l2 < lpad; l2 += 2) {
         const float av = arow[l2];
         const bool in = lc + l2 + (lane >> 5) < L;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int tile = nbase + wv + 4 * j;
-          if (tile < nt) {
-            const float bv = (in && tile * 32 + (lane & 31) < D) ? xrow[(size_t)l2 * D + tile * 32] : 0.f;
+          if (j < njt) {
+            const float bv = (in && col + 128 * j < D) ? xrow[(size_t)l2 * D + (nbase + wv + 4 * j) * 32] : 0.f;
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
           }
         }
       }
       __syncthreads();
     }
+    // (the 16 rows' range predicates do not depend on the tile pass: the compiler hoisted all 32 of them out of the nbase loop
+    //  and held them as SGPR pairs across the contraction — the 18 spilled SGPRs of round 5.  An opaque base keeps them here.)
+    int tb = t0 + 4 * (lane >> 5);
+    asm("" : "+v"(tb));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int tile = nbase + wv + 4 * j;
       if (tile >= nt) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int t = tb + (r & 3) + 8 * (r >> 2);
         if (t < T_out && tile * 32 + (lane & 31) < D) out[(row0 + t) * D + tile * 32 + (lane & 31)] = t < t_lim ? acc[j][r] : 0.f;
       }
     }

@@ -494,3 +494,17 @@ def test_header_is_plain_c_and_host_entry_points_work_from_c(lib, tmp_path):
     assert r.returncode == 0 and "C caller ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
     # the struct the C side sees is the struct the ctypes binding declares
     assert f"sizeof(ns_config)={C.sizeof(L.NsConfig)} " in r.stdout
+
+
+def test_no_kernel_spills_registers():
+    """Register hygiene gate (round-5 review): no kernel of the GEMM / row-operator sources spills a VGPR or an SGPR or uses
+    scratch memory — tools/kernel_resources.py compiles the source for gfx950 (hipcc cross-compiles without a GPU) and reads the
+    kernels' metadata.  Round 5 shipped 36-43 spilled SGPRs in the two-pass full-row tiles, 10-18 in two ticketed rungs and 18 in
+    k_gauss_upsample; profiles/r06_kernel_resources.txt is the table for all five sources."""
+    import subprocess
+    import sys
+
+    for src in ("gemm_conv.hip", "rowops.hip"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), os.path.join(ROOT, "smart-nar_fast_tts_amd", "csrc", src),
+                            "--assert-no-spill"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (src, r.stdout[-2000:], r.stderr[-2000:])

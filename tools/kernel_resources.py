@@ -25,6 +25,7 @@ def main():
     ap.add_argument("src")
     ap.add_argument("--grep", default="")
     ap.add_argument("--rev", default=None)
+    ap.add_argument("--assert-no-spill", action="store_true", help="exit 1 when any listed kernel spills a register or uses scratch (hot-path hygiene gate)")
     ap.add_argument("-I", dest="inc", action="append", default=[], help="extra include directory (lab harnesses: -I smart-nar_fast_tts_amd/csrc)")
     a = ap.parse_args()
     src = os.path.abspath(a.src)
@@ -85,14 +86,19 @@ def main():
     rows = [k for k in kern if "name" in k]
     dm = subprocess.run(["c++filt"], input="\n".join(k["name"] for k in rows), capture_output=True, text=True).stdout.splitlines()
     print(f"{'vgpr':>5} {'agpr':>5} {'sgpr':>5} {'vspill':>6} {'sspill':>6} {'scratch':>7} {'lds':>7} {'wg':>5} {'mfma':>5} {'dma':>4} {'dsrd':>5} {'vm0':>4}  kernel")
+    bad = []
     for k, d in sorted(zip(rows, dm), key=lambda x: x[1]):
         if a.grep and a.grep not in d:
             continue
+        if any(int(k.get(f, 0) or 0) for f in ("vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size")):
+            bad.append(d)
         c = counts.get(k["name"], {})
         short = re.sub(r"\(.*", "", d).replace("void ns::", "")
         print(f"{k.get('vgpr_count', '?'):>5} {k.get('agpr', '?'):>5} {k.get('sgpr_count', '?'):>5} {k.get('vgpr_spill_count', '?'):>6} {k.get('sgpr_spill_count', '?'):>6} "
               f"{k.get('private_segment_fixed_size', '?'):>7} {k.get('group_segment_fixed_size', '?'):>7} {k.get('max_flat_workgroup_size', '?'):>5} "
               f"{c.get('mfma', '?'):>5} {c.get('dma', '?'):>4} {c.get('ds_read', '?'):>5} {c.get('waitvm0', '?'):>4}  {short}")
+    if a.assert_no_spill and bad:
+        sys.exit("kernels that spill or use scratch:\n  " + "\n  ".join(bad))
 
 
 if __name__ == "__main__":
