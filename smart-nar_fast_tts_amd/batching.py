@@ -131,21 +131,30 @@ def synthesize(model, batchs, preprocess_config, device="cuda", p_control: float
 # or cut in two is therefore a question to put to the plan's own cost model for the dominant launch (the decoder FFN's k=9
 # Conv1D-as-GEMM, ~40 % of a forward), not a list of batch sizes tuned at one utterance length (round 4's (1, 2, 4, 8, 12, 16, 24, 32)
 # was right for ~1000-frame utterances only).
+# (Both constants are fitted on ONE chip and ONE model: LJSpeech d = 256, 4 decoder layers, MI355X, profiles/r06_batch_size_sweep.txt.
+#  Another width or chip keeps the SHAPE of the rule — time follows rows through the plan — and should re-fit them, or pass `cost=`.)
 FORWARD_FIXED_US = 450.0   # what a forward costs before its rows count: phase 1 of a small batch, ~55 launch floors, the hand-over
 FORWARD_PER_W1 = 2.4       # whole phase 2 over its FFN w_1 launches (config 2: 5.2 ms against 4 x 0.54 ms)
+ROWS_LINEAR_US = 0.30      # fallback without the native library: us per phase-2 row (config 2: 5.3 ms over 16 160 rows, less the fixed part)
 
 
 def forward_cost_us(rows: int, model_config=None, lib=None) -> float:
     """Modelled time of one forward whose phase 2 runs on ``rows`` rows, from the launch plan's estimate for the dominant launch
     (``ns_plan_gemm``'s 8th output, host-side: no GPU needed); below the planner's range (a few hundred rows) the small-grid
-    ladder's floor for that launch."""
+    ladder's floor for that launch.  The estimate is the plan's own, including the 1-3 % tie-break margin it prices its candidates
+    with.  This is a host-side collate helper: when the native library cannot be loaded (no build on this machine) it falls back to
+    a rows-linear cost instead of failing — bucketing then still cuts where padding is removed, only without the plan's steps."""
     import ctypes as C
 
     from . import _lib, workload as wl
 
     t = (model_config or wl.LJSPEECH_MODEL_CONFIG)["transformer"]
     d, d_inner, k1, layers = t["decoder_hidden"], t["conv_filter_size"], t["conv_kernel_size"][0], t["decoder_layer"]
-    lib = lib or _lib.load()
+    if lib is None:
+        try:
+            lib = _lib.load()
+        except (ImportError, OSError, AttributeError):
+            return FORWARD_FIXED_US + ROWS_LINEAR_US * max(int(rows), 0) * (layers / 4.0) * (d / 256.0) ** 2
     o = (C.c_int32 * 8)()
     chunks = k1 * (d // 32)
     if rows > 0 and lib.ns_plan_gemm(int(rows), d_inner, d, k1, o):

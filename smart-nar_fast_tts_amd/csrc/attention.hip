@@ -674,8 +674,25 @@ int attention_split(int B, int S, int H, int dk) {
 // true when a dense launch of this shape can take the ticketed strip path (the only attention path that draws tickets): the
 // caller spends attention_ticket_ints(B, S, H) of its phase's ticket block only then — the planner's key split of a LARGE launch
 // (k_attention + k_attention_merge) needs the partials scratch but no tickets
+// (the SAME acceptance test launch_strips applies: a launch of few workgroups whose strips would each sweep more than 4 key tiles per
+//  wave — B = 3 at T ~ 2000 — takes k_attention + k_attention_merge instead, and a slice drawn for it would be burnt from the phase's
+//  ticket block for nothing, pushing later GEMM + LayerNorm launches to their two-launch form; round-5 advice)
+static int strip_split(long strips, int tiles) {
+  int nsplit = (int)((256 + strips - 1) / strips);
+  if (nsplit > (tiles + 3) / 4) nsplit = (tiles + 3) / 4;   // at least one key tile per wave
+  if (nsplit > ATT_STRIP_SPLIT_MAX) nsplit = ATT_STRIP_SPLIT_MAX;
+  return nsplit < 1 ? 1 : nsplit;
+}
+static int strip_tiles_per_range(int tiles, int nsplit) {
+  const int tpr = (tiles + 4 * nsplit - 1) / (4 * nsplit);
+  const int n2 = ((tiles + tpr - 1) / tpr + 3) / 4;           // no workgroup of empty ranges
+  return (tiles + 4 * n2 - 1) / (4 * n2);
+}
 bool attention_uses_tickets(int B, int S, int H) {
-  return B > 0 && S > 0 && (long)((S + 127) / 128) * H * B < ATT_SPLIT_MAX_BLOCKS;
+  if (B <= 0 || S <= 0 || (long)((S + 127) / 128) * H * B >= ATT_SPLIT_MAX_BLOCKS) return false;
+  const int tiles = (S + 31) / 32;
+  // (with the scratch the caller reserves for a split; a launch that ends up unsplit for lack of scratch draws no ticket either way)
+  return strip_tiles_per_range(tiles, strip_split((long)tiles * H * B, tiles)) <= 4;
 }
 
 // packed rows: the work list of att_wgs (128-query tile, head) workgroups, longest utterance (S frames) first

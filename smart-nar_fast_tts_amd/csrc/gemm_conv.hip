@@ -779,6 +779,12 @@ int conv_gemm_row_tile(int M, int N, int K) {
 }
 
 static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bool allow_split, const LaunchTiming* tm);
+// the tall tile of the one-tile-per-launch rules (NS_PLAN=0): 256 x 256, or — for a long contraction that accumulates in chunks —
+// 128 x 256, the tallest tile with room for the second accumulator set (same rows, twice the rounds)
+static hipError_t launch_tall(const ConvGemm& p, hipStream_t st, const LaunchTiming* tm) {
+  if (p.KW * p.Cin > 256 && acc_chunk_k() > 0) return launch_t<128, 256, 32, 1, 4, 4>(p, st, tm);
+  return launch_t<256, 256, 32, 1, 8, 2>(p, st, tm);
+}
 hipError_t launch_conv_gemm(const ConvGemm& p, hipStream_t st, const LaunchTiming* tm) { return launch_conv_gemm_impl(p, st, true, tm); }
 
 static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bool allow_split, const LaunchTiming* tm) {
@@ -885,7 +891,7 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
   if (bk32 && p.N >= 512 && wgs(rows64, 256) >= 400) {
     auto fill = [](long n) { return (double)n / (double)(((n + 255) / 256) * 256); };  // of the last round, one workgroup per CU
     const long c256 = wgs((p.M + 255) / 256, 256), c128 = wgs((p.M + 127) / 128, 256);
-    if (c256 >= 200 && c256 <= 512 && fill(c256) >= 0.95) return launch_t<256, 256, 32, 1, 8, 2>(p, st, tm);  // measured for one and two rounds only
+    if (c256 >= 200 && c256 <= 512 && fill(c256) >= 0.95) return launch_tall(p, st, tm);  // measured for one and two rounds only
     if (c128 <= 512 && fill(c128) >= 0.95) return launch_t<128, 256, 32, 1, 4, 4>(p, st, tm);
     // A row count somewhat above one or two FULL rounds of the 256x256 tile (packed variable-length batches: M is whatever
     // the utterances add up to; a uniform batch of one utterance more than a round holds) and too small for the many-round
@@ -900,7 +906,7 @@ static hipError_t launch_conv_gemm_impl(const ConvGemm& p_in, hipStream_t st, bo
       const long r256 = 256 * per;
       const long n = p.M / r256 > 2 ? 2 : p.M / r256;
       const LaunchTiming t0{tm ? tm->start : nullptr, nullptr}, t1{nullptr, tm ? tm->stop : nullptr};
-      const hipError_t e = launch_t<256, 256, 32, 1, 8, 2>(row_range(p, 0, (int)(n * r256)), st, &t0);
+      const hipError_t e = launch_tall(row_range(p, 0, (int)(n * r256)), st, &t0);
       if (e != hipSuccess) return e;
       return launch_conv_gemm_impl(row_range(p, (int)(n * r256), (int)(p.M - n * r256)), st, false, &t1);
     }

@@ -213,7 +213,11 @@ class FastSpeech2Align:
         return self.to("cuda" if device is None else device)
 
     def state_dict(self):
-        return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in self._sd.items())
+        """What load_state_dict received — or, before anything was loaded, the constructor-equivalent initialisation that
+        parameters() / named_parameters() report and the first forward uploads (an nn.Module's state_dict() on a fresh model
+        holds the full set too: torch.save(model.state_dict()) must not write an empty file).  A model whose weights arrived as
+        packed arena bytes (adopt_arena) has no per-parameter host copy and raises."""
+        return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in self._ensure_host_copy().items())
 
     # What code that introspects an nn.Module finds (model/fastspeech2_align.py:13-28, utils/model.py:31-35 counts parameters):
     # HOST copies of what load_state_dict received — the device copy is one packed arena (tap-major convolutions, fused QKV,

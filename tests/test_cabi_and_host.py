@@ -385,6 +385,11 @@ def test_introspection_before_a_load_does_not_count_as_loaded(tmp_path, monkeypa
     m._device = torch.device("cuda", 0)
     shown = dict(m.named_parameters())
     assert len(shown) > 80 and len(m._sd) == 0 and not m._loaded and m._user_keys == set()
+    # state_dict() of a fresh model holds the same full set (parameters + buffers), like nn.Module's — not {} (round-5 advice) —
+    # and looking at it does not count as a load either
+    fresh = m.state_dict()
+    assert set(shown) <= set(fresh) and len(fresh) == len(shown) + len(dict(m.named_buffers())) and len(m._sd) == 0
+    np.testing.assert_array_equal(fresh["mel_linear.weight"].numpy(), shown["mel_linear.weight"].numpy())
     good = wl.synth_state_dict(cfg)
     part = {k: v for k, v in good.items() if not k.startswith("mel_linear.")}
     with pytest.raises(RuntimeError, match="missing key.*mel_linear.weight"):
