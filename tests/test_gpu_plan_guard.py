@@ -38,7 +38,7 @@ def test_planned_forward_is_never_slower_than_the_unplanned_rules():
         for plan in ("0", "1"):
             runs[plan].append(_sweep({"NS_PLAN": plan}))
     report = []
-    worst = 0.0
+    worst = -1.0
     for b in (int(x) for x in BATCHES.split(",")):
         t1, t0 = min(r[b] for r in runs["1"]), min(r[b] for r in runs["0"])
         report.append(f"B={b}: planned {t1:.3f} ms, rules {t0:.3f} ms ({100 * (t1 / t0 - 1):+.1f} %)")
