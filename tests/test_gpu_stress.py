@@ -63,6 +63,13 @@ def test_ticketed_epilogues_match_the_two_launch_form_bit_for_bit():
     # rows the ticketed 32 x 128 one while other launches of the same forwards run on the family's tiles
     cases.append(("uniform batch of 18", cfg1, sd1, wl.synth_inputs(18, 128, seed=6)))
     cases.append(("uniform batch of 5", cfg1, sd1, wl.synth_inputs(5, 128, seed=7)))
+    # dense decoder attention with the planner's key split (B = 9: 3 ranges, B = 17: 4): the last range to arrive merges inside
+    # k_attention (round 6) — against split-key k_attention + k_attention_merge, which the two-launch form still takes
+    cases.append(("uniform batch of 9", cfg1, sd1, wl.synth_inputs(9, 128, seed=8)))
+    cases.append(("uniform batch of 17", cfg1, sd1, wl.synth_inputs(17, 128, seed=9)))
+    # a long single utterance: few workgroups, up to 16 key ranges through k_attention (the strip kernel declines > 4 tiles per wave)
+    sd31 = wl.synth_state_dict(cfg1, seed=0, frames_per_phoneme=31.0)
+    cases.append(("3 long utterances", cfg1, sd31, wl.synth_inputs(3, 100, seed=10)))
     built = {}
     for name, cfg, sd, inp in cases:
         key = id(sd)
