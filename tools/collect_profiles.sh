@@ -9,7 +9,7 @@
 # MI355X_MICROARCH.md prescribes).  bench.py runs with --no-extras under the profiler: the trace then holds exactly
 # (warmup + steps) forwards of the workload, nothing else.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
