@@ -535,6 +535,15 @@ int conv_gemm_acc_chunk() {
   return v;
 }
 static int acc_chunk_k() { return conv_gemm_acc_chunk(); }
+// contraction length above which a launch must run on a tile with the second accumulator set: 512.  Up to there a tall tile's one
+// sequential sum is at most 256 MFMA steps — K = 256 measured level with torch's CPU sums, K = 512 (the d = 512 model's QKV / fc) is
+// sqrt(2) of that on two of a block's six contractions — and the tall tiles are worth 0.8 % of a config-4 forward (57.91 -> 57.45 ms,
+// same box; float64 ratios of profiles/r06_accuracy_vs_f64.md unchanged).  Wherever such a launch lands on a tile with room it chunks anyway.
+// NS_LONG_K (>= 256) for A/B runs.
+static int long_k_threshold() {
+  static const int v = [] { const char* e = getenv("NS_LONG_K"); const int k = e ? atoi(e) : 512; return k >= 256 ? k : 256; }();
+  return v;
+}
 // a tile with room for the second accumulator set: <= 32 accumulator registers per lane
 static constexpr bool tile_chunks(int bm, int bn, int waves) { return bm * bn / (64 * waves) <= 32; }
 
@@ -689,10 +698,10 @@ static RowPlan plan_rows(long M, int N, int chunks) {
   // short contractions (QKV, fc: K = d, 8-16 chunks): prologue and epilogue weigh as much as the K loop, and three 64x128 workgroups
   // per CU interleave them better than one tall 16-wave tile — settled by forward A/B in round 3 (config 2 5.476 -> 5.456 ms) and
   // again by the model's own margin in round 4 (B = 20 QKV: 256x256 one step 83 us in the lab against 77 us on 64x128)
-  // long contractions (K > 256) stay on the tiles that accumulate in chunks (k_conv_gemm ACC2): 128 x 256 and below — the 256 x 256
+  // long contractions (K > 512, long_k_threshold) stay on the tiles that accumulate in chunks (k_conv_gemm ACC2): 128 x 256 and below — the 256 x 256
   // tile's 64 accumulator registers per lane leave no room for the second set.  (Round 5 ran the decoder's k=9 GEMM on it at
   // B = 16: 543 us per launch against 554 on two rounds of 128 x 256 — 0.8 % of a forward for 3.7x less rounding error.)
-  const bool long_k = chunks > 8 && acc_chunk_k() > 0;
+  const bool long_k = chunks * 32 > long_k_threshold() && acc_chunk_k() > 0;
   const int first = chunks <= 16 ? T64W : long_k ? T128 : T256;
   for (int t = first; t < N_TILES; ++t) {
     if (kTile[t].bn > N && t != T32 && t != T64N && t != T64) continue;  // (a 256-wide tile on a narrower output: never)
