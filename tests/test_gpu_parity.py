@@ -73,8 +73,9 @@ def close(got, ref, tol, what):
     got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
-    bound = tol + 1e-5 * np.abs(ref)
-    assert np.all(err <= bound), (what, "max-abs err", float(err.max()), "tol", tol)
+    # (absolute, as north_star states it: round 5 added 1e-5 |ref| of slack — 5e-3 on a pitch of 500 — which the chunked accumulation
+    # of round 6 no longer needs: worst pitch error 5.5e-4 at |v| ~ 500, worst mel error 3.6e-6)
+    assert np.all(err <= tol), (what, "max-abs err", float(err.max()), "tol", tol)
     return float(err.max())
 
 
