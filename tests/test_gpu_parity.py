@@ -1302,3 +1302,47 @@ def test_bits_across_launch_plans():
         print("MFMA tile edges seen:", mfs)
     finally:
         m.packed_rows = keep
+
+
+@pytest.mark.parametrize("name", ["pin_cfg1_single", "pin_cfg2_b16", "pin_cfg3_b128_sharded", "pin_cfg4_d512", "pin_cfg5_longform"])
+def test_free_running_at_baseline_size(name):
+    """north_star's criterion as worded — FREE-RUNNING, nothing pinned — at BASELINE sizes against the reference's own values
+    (tests/golden/pin_cfg*.npz): integers identical; every bucket decision that differs from the reference's sits on a bin edge
+    (within EDGE_REL, by one bucket); and every utterance in which NO decision differs has its mel and PostNet mel within 1e-3 on
+    every stored frame.  An utterance with an edge flip is the case the reference itself produces against itself
+    (profiles/r06_reference_self_deviation.md: mkldnn off flips one energy decision of pin_cfg3 and moves 290 frames by up to
+    1.07); it is counted and reported, and the bucket-pinned tests above cover it."""
+    from oracle import parity
+
+    meta, z = load_golden(name)
+    cfg, sd, m = gpu_model(meta)
+    out = run_gpu(m, z, meta)
+    assert np.array_equal(out[9].cpu().numpy(), z["mel_lens"]) and np.array_equal(out[5].cpu().numpy(), z["d_rounded"])
+    valid = ~z["mel_masks"]
+    pb, eb = np.asarray(sd["variance_adaptor.pitch_bins"]), np.asarray(sd["variance_adaptor.energy_bins"])
+    hit = np.zeros(valid.shape[0], dtype=bool)
+    n_flip = 0
+    for i, key, bins, edge in ((2, "p_predictions", pb, "p_edge_rel"), (3, "e_predictions", eb, "e_edge_rel")):
+        got, ref = parity.bucketize(out[i].cpu().numpy(), bins), parity.bucketize(z[key], bins)
+        flip = (got != ref) & valid
+        if key[0] == "p":
+            p_hit = flip.any(axis=1)
+        hit |= flip.any(axis=1)
+        n_flip += int(flip.sum())
+        if key[0] == "p":  # (an energy decision downstream of a flipped pitch decision is a consequence, not a flip of its own)
+            assert np.all(z[edge][flip] < EDGE_REL) and np.all(np.abs(got - ref)[flip] <= 1), (name, key, "flip away from an edge")
+        else:
+            own = flip & ~p_hit[:, None]
+            assert np.all(z[edge][own] < EDGE_REL) and np.all(np.abs(got - ref)[own] <= 1), (name, key, "flip away from an edge")
+    stride = int(meta["frame_stride"])
+    clean = ~hit
+    vs = valid[:, ::stride] & clean[:, None]
+    worst = 0.0
+    for i, key in ((0, "output_sub"), (1, "postnet_output_sub")):
+        err = np.abs(out[i].cpu().numpy()[:, ::stride].astype(np.float64) - z[key])[vs]
+        worst = max(worst, float(err.max()) if err.size else 0.0)
+    print(f"{name}: free-running, {int(clean.sum())} of {len(clean)} utterances without a differing decision: worst mel error {worst:.2e}; "
+          f"{n_flip} decisions differ (all on an edge) in {int(hit.sum())} utterance(s)")
+    assert worst < MEL_TOL, (name, worst)
+    assert clean.sum() >= len(clean) - 2, (name, "more than two utterances hit a bin edge", int(hit.sum()))
+    _MODEL.clear()
