@@ -188,9 +188,10 @@ def prepare_shard(batch, device="cuda", balance: str = "count", host_lens: bool 
     n = int(text_lens.shape[0])
     parts = shard_indices(text_lens, world, balance)
     idx = parts[rank]
+    texts = np.asarray(texts)
+    max_len = int(texts.shape[1]) if texts.ndim == 2 else int(max_len)  # (the padded width forward() sees, = max(text_lens) after collate)
     if len(idx) == 0:
         return Shard(idx, parts, None, n, world, rank, max_len, ids)
-    texts = np.asarray(texts)
     mine = ([ids[i] for i in idx], [raw_texts[i] for i in idx], np.asarray(speakers)[idx], np.ascontiguousarray(texts[idx]),
             np.ascontiguousarray(text_lens[idx]), int(texts.shape[1]))
     return Shard(idx, parts, to_device(mine, device, host_lens), n, world, rank, max_len, ids)
@@ -226,7 +227,7 @@ def forward_shard(model, shard: Shard, global_pad: bool = False, group=None, **f
 
     try:
         return model(*(shard.batch[2:]), max_mel_len=pad_to, **forward_kw)
-    except BaseException as e:
+    except Exception as e:
         if not joined:  # raised before the exchange: join it (flag set) so the other ranks do not wait for this one
             exchange_pad(0, True, dev, group)
             e._ns_peers_know = True
@@ -272,7 +273,7 @@ def synthesize_sharded(model, batch, preprocess_config, device="cuda", balance: 
             out = forward_shard(model, shard, global_pad, group, p_control=p_control, e_control=e_control)
     except PeerFailure:
         raise  # the pad exchange told EVERY rank: nobody goes on to the gather
-    except BaseException:
+    except Exception:
         if gather and shard.world > 1:
             # this rank alone knows: the others are on their way to the gather's all-gather.  Join it, marked, then re-raise.
             # (A failure that the global-pad exchange already announced is different: the others raised PeerFailure and are NOT
